@@ -1,0 +1,64 @@
+"""ctypes binding of libdyneval_hip.so (the C-ABI declared in include/dyneval.h).
+
+The product path has NO CPU fallback: if the shared library is missing or an entry point returns an error the
+caller gets an exception, never a silently different implementation."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdyneval_hip.so")
+_lib = None
+
+
+class DynError(RuntimeError):
+    pass
+
+
+class GemmDesc(ctypes.Structure):
+    """Mirror of dyn_gemm_desc (include/dyneval.h)."""
+    _fields_ = [
+        ("trans_a", ctypes.c_int32), ("trans_b", ctypes.c_int32),
+        ("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64),
+        ("alpha", ctypes.c_float), ("beta", ctypes.c_float),
+        ("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("sa1", ctypes.c_int64), ("sa2", ctypes.c_int64),
+        ("B", ctypes.c_void_p), ("ldb", ctypes.c_int64), ("sb1", ctypes.c_int64), ("sb2", ctypes.c_int64),
+        ("C", ctypes.c_void_p), ("ldc", ctypes.c_int64), ("sc1", ctypes.c_int64), ("sc2", ctypes.c_int64),
+        ("bias", ctypes.c_void_p),
+        ("nb1", ctypes.c_int64), ("nb2", ctypes.c_int64),
+        ("split_k", ctypes.c_int32),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
+    ]
+
+
+def load():
+    """Load the shared library once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DynError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C dynamic-asr-eval_amd/csrc`). "
+            "There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.dyn_last_error.restype = ctypes.c_char_p
+    lib.dyn_version.restype = ctypes.c_char_p
+    lib.dyn_arch.restype = ctypes.c_char_p
+    lib.dyn_gemm_f32_workspace_bytes.restype = ctypes.c_int64
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().dyn_last_error().decode("utf-8", "replace")
+        raise DynError(f"{what} failed with code {rc}: {msg}")
+
+
+def exported_symbols():
+    """Names declared in include/dyneval.h (used by the CPU-side ABI test)."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "dyneval.h")
+    text = open(hdr).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dyn_[a-z0-9_]+)\s*\(", text)))
