@@ -41,10 +41,10 @@ def load():
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C dynamic-asr-eval_amd/csrc`). "
             "There is no CPU fallback for the product path.")
     lib = ctypes.CDLL(LIB_PATH)
-    lib.dyn_last_error.restype = ctypes.c_char_p
-    lib.dyn_version.restype = ctypes.c_char_p
-    lib.dyn_arch.restype = ctypes.c_char_p
-    lib.dyn_gemm_f32_workspace_bytes.restype = ctypes.c_int64
+    for name, (restype, argtypes) in prototypes().items():
+        fn = getattr(lib, name)  # AttributeError here = header and library out of sync: fail loudly
+        fn.restype = restype
+        fn.argtypes = argtypes
     _lib = lib
     return lib
 
@@ -55,10 +55,41 @@ def check(rc, what=""):
         raise DynError(f"{what} failed with code {rc}: {msg}")
 
 
-def exported_symbols():
-    """Names declared in include/dyneval.h (used by the CPU-side ABI test)."""
+_CTYPES = {
+    "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+}
+_PROTOS = None
+
+
+def prototypes():
+    """Parse include/dyneval.h into {name: (restype, argtypes)} so the header is the single source of truth for
+    the binding (an int64_t passed as a bare Python int would otherwise be truncated to a C int)."""
+    global _PROTOS
+    if _PROTOS is not None:
+        return _PROTOS
     import re
     hdr = os.path.join(os.path.dirname(_HERE), "include", "dyneval.h")
     text = open(hdr).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(dyn_[a-z0-9_]+)\s*\(", text)))
+    text = re.sub(r"typedef struct \{.*?\} \w+;", "", text, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"([\w\s\*]+?)\b(dyn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        ret = ret.strip()
+        if ret == "const char*":
+            restype = ctypes.c_char_p
+        else:
+            restype = _CTYPES[ret]
+        argtypes = []
+        for a in [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]:
+            if "*" in a:
+                argtypes.append(ctypes.POINTER(GemmDesc) if "dyn_gemm_desc" in a else ctypes.c_void_p)
+            else:
+                argtypes.append(_CTYPES[a.replace("const ", "").split()[0]])
+        protos[name] = (restype, argtypes)
+    _PROTOS = protos
+    return protos
+
+
+def exported_symbols():
+    """Names declared in include/dyneval.h (used by the CPU-side ABI test)."""
+    return sorted(prototypes().keys())

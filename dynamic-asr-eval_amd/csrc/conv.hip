@@ -1,0 +1,414 @@
+// Convolutions of the conformer encoder, channels-last so every access is coalesced along C:
+//   * depthwise Conv1d (kernel KW <= 31, 'same' zero padding) of the conformer conv module, fwd / dgrad / wgrad;
+//   * the dw_striding x8 subsampling front-end: first 3x3 stride-2 conv (1 -> C channels, direct) and the
+//     3x3 stride-2 depthwise convs with the preceding SiLU fused into the load (pointwise 1x1 convs are GEMMs).
+// These are HBM-bound (a few FLOPs per byte): each thread owns one channel and slides over time so every
+// input element is loaded once per workgroup and reused from registers.
+// Reference call sites: upstream SCConformerXL conv module / subsampling reached through
+// model(audio_signal=...) (reference lcasr/lib.py:164,550; earnings_finetune/lcasr160rb1.yaml:10-15).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float silu_f(float x) { return x * dyn::sigmoidf_(x); }
+__device__ __forceinline__ float silu_grad(float x) {
+    const float s = dyn::sigmoidf_(x);
+    return s * (1.f + x * (1.f - s));
+}
+
+constexpr int TT = 32;  // time steps per workgroup tile
+
+// y[b,t,c] = bias[c] + sum_j w[c,j] * x[b, t + j - P, c],  P = (KW-1)/2.   FLIP => dgrad (w index reversed).
+template <int KW, bool FLIP>
+__global__ __launch_bounds__(256) void dwconv1d_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int64_t T,
+                                                        int C, float beta) {
+    constexpr int P = (KW - 1) / 2;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t b = blockIdx.z;
+    const int64_t t0 = (int64_t)blockIdx.x * TT;
+    float wk[KW];
+#pragma unroll
+    for (int j = 0; j < KW; ++j) wk[j] = w[(int64_t)c * KW + (FLIP ? KW - 1 - j : j)];
+    const float bv = bias ? bias[c] : 0.f;
+    const float* xb = x + b * T * C + c;
+    float* yb = y + b * T * C + c;
+    float win[KW];
+#pragma unroll
+    for (int j = 0; j < KW - 1; ++j) {
+        const int64_t t = t0 + j - P;
+        win[j + 1] = (t >= 0 && t < T) ? xb[t * C] : 0.f;
+    }
+    for (int k = 0; k < TT; ++k) {
+        const int64_t t = t0 + k;
+        if (t >= T) break;
+#pragma unroll
+        for (int j = 0; j < KW - 1; ++j) win[j] = win[j + 1];
+        const int64_t tn = t + P;
+        win[KW - 1] = tn < T ? xb[tn * C] : 0.f;
+        float acc = bv;
+#pragma unroll
+        for (int j = 0; j < KW; ++j) acc += wk[j] * win[j];
+        yb[t * C] = beta != 0.f ? acc + beta * yb[t * C] : acc;
+    }
+}
+
+// partial[(tile), j, c] = sum_{t in tile} dy[b,t,c] * x[b, t + j - P, c];   partial_b[(tile), c] = sum dy
+template <int KW>
+__global__ __launch_bounds__(256) void dwconv1d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ partial_w, float* __restrict__ partial_b,
+                                                              int64_t T, int C, int64_t t_per_block) {
+    constexpr int P = (KW - 1) / 2;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t b = blockIdx.z;
+    const int64_t t0 = (int64_t)blockIdx.x * t_per_block;
+    const int64_t t1 = (t0 + t_per_block < T) ? t0 + t_per_block : T;
+    const float* xb = x + b * T * C + c;
+    const float* gb = dy + b * T * C + c;
+    float acc[KW], win[KW];
+    float accb = 0.f;
+#pragma unroll
+    for (int j = 0; j < KW; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < KW - 1; ++j) {
+        const int64_t t = t0 + j - P;
+        win[j + 1] = (t >= 0 && t < T) ? xb[t * C] : 0.f;
+    }
+    for (int64_t t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int j = 0; j < KW - 1; ++j) win[j] = win[j + 1];
+        const int64_t tn = t + P;
+        win[KW - 1] = tn < T ? xb[tn * C] : 0.f;
+        const float g = gb[t * C];
+        accb += g;
+#pragma unroll
+        for (int j = 0; j < KW; ++j) acc[j] += g * win[j];
+    }
+    const int64_t tile = (int64_t)blockIdx.z * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int j = 0; j < KW; ++j) partial_w[(tile * C + c) * KW + j] = acc[j];
+    partial_b[tile * C + c] = accb;
+}
+
+// ---- subsampling: first conv, 1 input channel, 3x3, stride 2, pad 1:  x [B, T, F] -> z [B, To, Fo, C] ----
+__global__ __launch_bounds__(256) void conv2d_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ z,
+                                                                int64_t T, int F, int64_t To, int Fo, int C) {
+    // One workgroup = one (b, to) row, looping over fo; thread = channel (C <= 256 per x-block).
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    const int64_t to = blockIdx.x, b = blockIdx.z;
+    if (c >= C) return;
+    float wk[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) wk[j] = w[c * 9 + j];
+    const float bv = bias[c];
+    const float* xb = x + b * T * F;
+    float* zb = z + ((b * To + to) * Fo) * C + c;
+    for (int fo = 0; fo < Fo; ++fo) {
+        float acc = bv;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int64_t t = 2 * to + dt - 1;
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                const int f = 2 * fo + df - 1;
+                const float v = (t >= 0 && t < T && f >= 0 && f < F) ? xb[t * F + f] : 0.f;  // wave-uniform load
+                acc += wk[dt * 3 + df] * v;
+            }
+        }
+        zb[(int64_t)fo * C] = acc;
+    }
+}
+
+// wgrad of the first conv: partial[(b,to-chunk), c, 9] and bias partial.
+__global__ __launch_bounds__(256) void conv2d_first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                                  float* __restrict__ partial_w, float* __restrict__ partial_b,
+                                                                  int64_t T, int F, int64_t To, int Fo, int C,
+                                                                  int64_t to_per_block) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    const int64_t b = blockIdx.z;
+    if (c >= C) return;
+    const int64_t to0 = (int64_t)blockIdx.x * to_per_block;
+    const int64_t to1 = (to0 + to_per_block < To) ? to0 + to_per_block : To;
+    float acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j] = 0.f;
+    float accb = 0.f;
+    const float* xb = x + b * T * F;
+    for (int64_t to = to0; to < to1; ++to) {
+        const float* gz = dz + ((b * To + to) * Fo) * C + c;
+        for (int fo = 0; fo < Fo; ++fo) {
+            const float g = gz[(int64_t)fo * C];
+            accb += g;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                const int64_t t = 2 * to + dt - 1;
+#pragma unroll
+                for (int df = 0; df < 3; ++df) {
+                    const int f = 2 * fo + df - 1;
+                    const float v = (t >= 0 && t < T && f >= 0 && f < F) ? xb[t * F + f] : 0.f;
+                    acc[dt * 3 + df] += g * v;
+                }
+            }
+        }
+    }
+    const int64_t tile = (int64_t)blockIdx.z * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) partial_w[(tile * C + c) * 9 + j] = acc[j];
+    partial_b[tile * C + c] = accb;
+}
+
+// ---- subsampling: depthwise 3x3 stride 2 pad 1 over (T, F), input activation SiLU fused into the load ----
+//   u[b,to,fo,c] = bias[c] + sum_{dt,df} w[c,dt,df] * silu(z[b, 2to+dt-1, 2fo+df-1, c])
+__global__ __launch_bounds__(256) void dwconv2d_s2_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ u,
+                                                               int64_t T, int F, int64_t To, int Fo, int C) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    const int64_t to = blockIdx.x, b = blockIdx.z;
+    if (c >= C) return;
+    float wk[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) wk[j] = w[c * 9 + j];
+    const float bv = bias[c];
+    const float* zb = z + b * T * F * C + c;
+    float* ub = u + ((b * To + to) * Fo) * C + c;
+    for (int fo = 0; fo < Fo; ++fo) {
+        float acc = bv;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int64_t t = 2 * to + dt - 1;
+            if (t < 0 || t >= T) continue;
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                const int f = 2 * fo + df - 1;
+                if (f < 0 || f >= F) continue;
+                acc += wk[dt * 3 + df] * silu_f(zb[(t * F + f) * C]);
+            }
+        }
+        ub[(int64_t)fo * C] = acc;
+    }
+}
+
+// dz[b,t,f,c] = silu'(z) * sum_{(to,dt),(fo,df): 2to+dt-1=t, 2fo+df-1=f} w[c,dt,df] * du[b,to,fo,c]
+__global__ __launch_bounds__(256) void dwconv2d_s2_dgrad_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                                                 const float* __restrict__ du, float* __restrict__ dz,
+                                                                 int64_t T, int F, int64_t To, int Fo, int C) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    const int64_t t = blockIdx.x, b = blockIdx.z;
+    if (c >= C) return;
+    float wk[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) wk[j] = w[c * 9 + j];
+    const float* gb = du + b * To * Fo * C + c;
+    for (int f = 0; f < F; ++f) {
+        float acc = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int64_t tt = t + 1 - dt;  // = 2*to
+            if (tt < 0 || (tt & 1)) continue;
+            const int64_t to = tt >> 1;
+            if (to >= To) continue;
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                const int ff = f + 1 - df;
+                if (ff < 0 || (ff & 1)) continue;
+                const int fo = ff >> 1;
+                if (fo >= Fo) continue;
+                acc += wk[dt * 3 + df] * gb[(to * Fo + fo) * C];
+            }
+        }
+        const int64_t idx = ((b * T + t) * F + f) * C + c;
+        dz[idx] = acc * silu_grad(z[idx]);
+    }
+}
+
+__global__ __launch_bounds__(256) void dwconv2d_s2_wgrad_kernel(const float* __restrict__ z, const float* __restrict__ du,
+                                                                 float* __restrict__ partial_w, float* __restrict__ partial_b,
+                                                                 int64_t T, int F, int64_t To, int Fo, int C,
+                                                                 int64_t to_per_block) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    const int64_t b = blockIdx.z;
+    if (c >= C) return;
+    const int64_t to0 = (int64_t)blockIdx.x * to_per_block;
+    const int64_t to1 = (to0 + to_per_block < To) ? to0 + to_per_block : To;
+    float acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j] = 0.f;
+    float accb = 0.f;
+    const float* zb = z + b * T * F * C + c;
+    for (int64_t to = to0; to < to1; ++to) {
+        const float* gz = du + ((b * To + to) * Fo) * C + c;
+        for (int fo = 0; fo < Fo; ++fo) {
+            const float g = gz[(int64_t)fo * C];
+            accb += g;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                const int64_t t = 2 * to + dt - 1;
+                if (t < 0 || t >= T) continue;
+#pragma unroll
+                for (int df = 0; df < 3; ++df) {
+                    const int f = 2 * fo + df - 1;
+                    if (f < 0 || f >= F) continue;
+                    acc[dt * 3 + df] += g * silu_f(zb[(t * F + f) * C]);
+                }
+            }
+        }
+    }
+    const int64_t tile = (int64_t)blockIdx.z * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) partial_w[(tile * C + c) * 9 + j] = acc[j];
+    partial_b[tile * C + c] = accb;
+}
+
+__global__ void reduce_tiles_kernel(const float* __restrict__ partial, float* out, int64_t P, int64_t n, float beta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int64_t p = 0; p < P; ++p) s += partial[p * n + i];
+        out[i] = (beta != 0.f ? beta * out[i] : 0.f) + s;
+    }
+}
+
+template <bool FLIP>
+int launch_dw1d(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t T, int64_t C, int64_t KW,
+                float beta, hipStream_t st) {
+    dim3 grid((unsigned)dyn::cdiv(T, TT), (unsigned)dyn::cdiv(C, 256), (unsigned)B), blk(256);
+#define GO(K) hipLaunchKernelGGL((dwconv1d_kernel<K, FLIP>), grid, blk, 0, st, x, w, bias, y, T, (int)C, beta)
+    switch (KW) {
+        case 3: GO(3); break; case 5: GO(5); break; case 7: GO(7); break; case 9: GO(9); break;
+        case 15: GO(15); break; case 31: GO(31); break;
+        default: dyn::set_error("dwconv1d: unsupported kernel width %lld", (long long)KW); return DYN_E_UNSUPPORTED;
+    }
+#undef GO
+    return dyn::check_launch("dyn_dwconv1d");
+}
+
+inline int64_t wgrad_tiles(int64_t B, int64_t T, int64_t* per_block) {
+    int64_t chunks = dyn::cdiv(T, 64);
+    if (chunks > 128) chunks = 128;
+    if (chunks < 1) chunks = 1;
+    *per_block = dyn::cdiv(T > 0 ? T : 1, chunks);
+    chunks = dyn::cdiv(T > 0 ? T : 1, *per_block);
+    return chunks;
+}
+
+}  // namespace
+
+extern "C" int dyn_dwconv1d_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t T, int64_t C,
+                                int64_t KW, void* stream) {
+    DYN_REQUIRE(x && w && y && B >= 0 && T >= 0 && C > 0, DYN_E_ARG, "dyn_dwconv1d_fwd: bad arguments");
+    if (B == 0 || T == 0) return DYN_OK;
+    return launch_dw1d<false>(x, w, bias, y, B, T, C, KW, 0.f, (hipStream_t)stream);
+}
+
+extern "C" int dyn_dwconv1d_dgrad(const float* dy, const float* w, float* dx, int64_t B, int64_t T, int64_t C, int64_t KW,
+                                  float dx_beta, void* stream) {
+    DYN_REQUIRE(dy && w && dx && B >= 0 && T >= 0 && C > 0, DYN_E_ARG, "dyn_dwconv1d_dgrad: bad arguments");
+    if (B == 0 || T == 0) return DYN_OK;
+    return launch_dw1d<true>(dy, w, nullptr, dx, B, T, C, KW, dx_beta, (hipStream_t)stream);
+}
+
+extern "C" int64_t dyn_dwconv1d_wgrad_workspace_bytes(int64_t B, int64_t T, int64_t C, int64_t KW) {
+    int64_t per;
+    const int64_t tiles = wgrad_tiles(B, T, &per) * B;
+    return tiles * C * (KW + 1) * (int64_t)sizeof(float);
+}
+
+extern "C" int dyn_dwconv1d_wgrad(const float* x, const float* dy, float* dw, float* dbias, float beta, int64_t B, int64_t T,
+                                  int64_t C, int64_t KW, void* workspace, int64_t workspace_bytes, void* stream) {
+    DYN_REQUIRE(x && dy && dw && B >= 0 && T >= 0 && C > 0, DYN_E_ARG, "dyn_dwconv1d_wgrad: bad arguments");
+    if (B == 0 || T == 0) return DYN_OK;
+    int64_t per;
+    const int64_t chunks = wgrad_tiles(B, T, &per), tiles = chunks * B;
+    DYN_REQUIRE(workspace && workspace_bytes >= tiles * C * (KW + 1) * (int64_t)sizeof(float), DYN_E_WORKSPACE,
+                "dyn_dwconv1d_wgrad: workspace too small");
+    float* pw = (float*)workspace;
+    float* pb = pw + tiles * C * KW;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)chunks, (unsigned)dyn::cdiv(C, 256), (unsigned)B), blk(256);
+#define GO(K) hipLaunchKernelGGL((dwconv1d_wgrad_kernel<K>), grid, blk, 0, st, x, dy, pw, pb, T, (int)C, per)
+    switch (KW) {
+        case 3: GO(3); break; case 5: GO(5); break; case 7: GO(7); break; case 9: GO(9); break;
+        case 15: GO(15); break; case 31: GO(31); break;
+        default: dyn::set_error("dwconv1d_wgrad: unsupported kernel width %lld", (long long)KW); return DYN_E_UNSUPPORTED;
+    }
+#undef GO
+    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)dyn::cdiv(C * KW, 256)), dim3(256), 0, st, pw, dw, tiles, C * KW, beta);
+    if (dbias) hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)dyn::cdiv(C, 256)), dim3(256), 0, st, pb, dbias, tiles, C, beta);
+    return dyn::check_launch("dyn_dwconv1d_wgrad");
+}
+
+extern "C" int dyn_conv2d_first_fwd(const float* x, const float* w, const float* bias, float* z, int64_t B, int64_t T,
+                                    int64_t F, int64_t C, void* stream) {
+    DYN_REQUIRE(x && w && bias && z && B >= 0 && T > 0 && F > 0 && C > 0, DYN_E_ARG, "dyn_conv2d_first_fwd: bad arguments");
+    if (B == 0) return DYN_OK;
+    const int64_t To = (T - 1) / 2 + 1, Fo = (F - 1) / 2 + 1;
+    dim3 grid((unsigned)To, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
+    hipLaunchKernelGGL(conv2d_first_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, z, T, (int)F, To, (int)Fo, (int)C);
+    return dyn::check_launch("dyn_conv2d_first_fwd");
+}
+
+extern "C" int64_t dyn_conv2d_wgrad_workspace_bytes(int64_t B, int64_t To, int64_t C) {
+    int64_t per;
+    const int64_t tiles = wgrad_tiles(B, To, &per) * B;
+    return tiles * C * 10 * (int64_t)sizeof(float);
+}
+
+extern "C" int dyn_conv2d_first_wgrad(const float* x, const float* dz, float* dw, float* dbias, float beta, int64_t B,
+                                      int64_t T, int64_t F, int64_t C, void* workspace, int64_t workspace_bytes, void* stream) {
+    DYN_REQUIRE(x && dz && dw && dbias && B >= 0 && T > 0 && F > 0 && C > 0, DYN_E_ARG, "dyn_conv2d_first_wgrad: bad arguments");
+    if (B == 0) return DYN_OK;
+    const int64_t To = (T - 1) / 2 + 1, Fo = (F - 1) / 2 + 1;
+    int64_t per;
+    const int64_t chunks = wgrad_tiles(B, To, &per), tiles = chunks * B;
+    DYN_REQUIRE(workspace && workspace_bytes >= tiles * C * 10 * (int64_t)sizeof(float), DYN_E_WORKSPACE,
+                "dyn_conv2d_first_wgrad: workspace too small");
+    float* pw = (float*)workspace;
+    float* pb = pw + tiles * C * 9;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)chunks, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
+    hipLaunchKernelGGL(conv2d_first_wgrad_kernel, grid, dim3(256), 0, st, x, dz, pw, pb, T, (int)F, To, (int)Fo, (int)C, per);
+    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)dyn::cdiv(C * 9, 256)), dim3(256), 0, st, pw, dw, tiles, C * 9, beta);
+    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)dyn::cdiv(C, 256)), dim3(256), 0, st, pb, dbias, tiles, C, beta);
+    return dyn::check_launch("dyn_conv2d_first_wgrad");
+}
+
+extern "C" int dyn_dwconv2d_s2_fwd(const float* z, const float* w, const float* bias, float* u, int64_t B, int64_t T,
+                                   int64_t F, int64_t C, void* stream) {
+    DYN_REQUIRE(z && w && bias && u && B >= 0 && T > 0 && F > 0 && C > 0, DYN_E_ARG, "dyn_dwconv2d_s2_fwd: bad arguments");
+    if (B == 0) return DYN_OK;
+    const int64_t To = (T - 1) / 2 + 1, Fo = (F - 1) / 2 + 1;
+    dim3 grid((unsigned)To, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
+    hipLaunchKernelGGL(dwconv2d_s2_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, w, bias, u, T, (int)F, To, (int)Fo, (int)C);
+    return dyn::check_launch("dyn_dwconv2d_s2_fwd");
+}
+
+extern "C" int dyn_dwconv2d_s2_dgrad(const float* z, const float* w, const float* du, float* dz, int64_t B, int64_t T,
+                                     int64_t F, int64_t C, void* stream) {
+    DYN_REQUIRE(z && w && du && dz && B >= 0 && T > 0 && F > 0 && C > 0, DYN_E_ARG, "dyn_dwconv2d_s2_dgrad: bad arguments");
+    if (B == 0) return DYN_OK;
+    const int64_t To = (T - 1) / 2 + 1, Fo = (F - 1) / 2 + 1;
+    dim3 grid((unsigned)T, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
+    hipLaunchKernelGGL(dwconv2d_s2_dgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, w, du, dz, T, (int)F, To, (int)Fo, (int)C);
+    return dyn::check_launch("dyn_dwconv2d_s2_dgrad");
+}
+
+extern "C" int dyn_dwconv2d_s2_wgrad(const float* z, const float* du, float* dw, float* dbias, float beta, int64_t B,
+                                     int64_t T, int64_t F, int64_t C, void* workspace, int64_t workspace_bytes, void* stream) {
+    DYN_REQUIRE(z && du && dw && dbias && B >= 0 && T > 0 && F > 0 && C > 0, DYN_E_ARG, "dyn_dwconv2d_s2_wgrad: bad arguments");
+    if (B == 0) return DYN_OK;
+    const int64_t To = (T - 1) / 2 + 1, Fo = (F - 1) / 2 + 1;
+    int64_t per;
+    const int64_t chunks = wgrad_tiles(B, To, &per), tiles = chunks * B;
+    DYN_REQUIRE(workspace && workspace_bytes >= tiles * C * 10 * (int64_t)sizeof(float), DYN_E_WORKSPACE,
+                "dyn_dwconv2d_s2_wgrad: workspace too small");
+    float* pw = (float*)workspace;
+    float* pb = pw + tiles * C * 9;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)chunks, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
+    hipLaunchKernelGGL(dwconv2d_s2_wgrad_kernel, grid, dim3(256), 0, st, z, du, pw, pb, T, (int)F, To, (int)Fo, (int)C, per);
+    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)dyn::cdiv(C * 9, 256)), dim3(256), 0, st, pw, dw, tiles, C * 9, beta);
+    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)dyn::cdiv(C, 256)), dim3(256), 0, st, pb, dbias, tiles, C, beta);
+    return dyn::check_launch("dyn_dwconv2d_s2_wgrad");
+}

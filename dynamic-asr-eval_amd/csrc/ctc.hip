@@ -1,0 +1,407 @@
+// CTC on the MI355X: greedy decode (argmax -> collapse repeats -> drop blank) and the log-sum-exp lattice
+// (alpha/beta recursions, loss and gradient with respect to the log-probabilities).
+//
+// Replaces, in the reference's dynamic-eval loop:
+//   * GreedyCTCDecoder(...)(out['final_posteriors'][-1].detach().cpu())   (reference lcasr/lib.py:498,559,565;
+//     run_dynamic_eval_full.py:53,100) — here the [T, V+1] posteriors never leave HBM, only the ids do;
+//   * torch.nn.CTCLoss(blank=V, reduction='sum') + its backward            (reference lcasr/lib.py:492,575,579;
+//     reduction='mean' in wav2vec2/lib.py:351).  The gradient follows torch's native formula
+//     (exp(lp) - exp(log(sum alpha*beta) + nll - lp)) * grad_out so results match the reference bit-for-formula.
+//
+// MI355X mapping: the lattice is latency-bound (T serial steps), so everything that is NOT serial is pulled out
+// of the scan and spread over the chip: the per-step gathers lp[t, label[s]] are pre-gathered by a full-grid kernel
+// into a contiguous [T, L] slab (coalesced, prefetchable), the scan itself is one 1024-thread workgroup per sample
+// with the previous lattice row in LDS and an 8-deep register prefetch of the slab, and the per-class reduction
+// of alpha*beta is one workgroup per time step.  All reductions run in a fixed order (no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int SCAN_T = 1024;  // threads of the serial scan workgroup
+constexpr int PD = 8;         // slab prefetch distance (time steps)
+
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+// ids[row] = argmax_c x[row, c]   (first maximum wins, as torch.argmax on CPU)
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int32_t* __restrict__ ids,
+                                                           int64_t rows, int C, int64_t ld) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float* xr = x + row * ld;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            const float v = xr[c];
+            if (better(v, c, bv, bi)) { bv = v; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) ids[row] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+
+// Collapse repeats and drop blanks: one workgroup per sequence, ordered compaction by block prefix sums.
+__global__ __launch_bounds__(1024) void ctc_collapse_kernel(const int32_t* __restrict__ ids, int32_t* __restrict__ out,
+                                                             int32_t* __restrict__ out_len, int64_t T, int64_t stride,
+                                                             int blank) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int64_t b = blockIdx.x;
+    const int32_t* in = ids + b * stride;
+    int32_t* o = out + b * stride;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int64_t t0 = 0; t0 < T; t0 += 1024) {
+        const int64_t t = t0 + threadIdx.x;
+        int id = -1, keep = 0;
+        if (t < T) {
+            id = in[t];
+            const int prev = t > 0 ? in[t - 1] : -1;
+            keep = (id != blank && id != prev) ? 1 : 0;
+        }
+        int incl = keep;  // inclusive wave scan
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) {
+            const int n = __shfl_up(incl, o2, 64);
+            if (lane >= o2) incl += n;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        const int b0 = base;
+        if (keep) o[b0 + woff + incl - 1] = id;
+        __syncthreads();
+        if (threadIdx.x == 1023) base = b0 + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_len[b] = base;
+}
+
+// ---- lattice ------------------------------------------------------------------------------------------------
+
+struct CtcDims {
+    int64_t T_max, B, C;
+    int64_t lp_st, lp_sb;  // element strides of log_probs for time and batch
+    int64_t S_max;
+    int64_t L_max;         // 2 * S_max + 1
+    int blank;
+};
+
+// Per sample: skip_ok[s] (the s-2 transition is allowed) and next_same[k] (next target index with the same label).
+__global__ __launch_bounds__(256) void ctc_prep_kernel(const int32_t* __restrict__ targets, const int32_t* __restrict__ tlen,
+                                                        int32_t* __restrict__ next_same, int32_t* __restrict__ is_first,
+                                                        int64_t S_max) {
+    const int64_t b = blockIdx.x;
+    const int S = tlen[b];
+    const int32_t* tg = targets + b * S_max;
+    for (int k = threadIdx.x; k < S; k += blockDim.x) {
+        const int c = tg[k];
+        int nx = -1;
+        for (int j = k + 1; j < S; ++j)
+            if (tg[j] == c) { nx = j; break; }
+        next_same[b * S_max + k] = nx;
+        int first = 1;
+        for (int j = 0; j < k; ++j)
+            if (tg[j] == c) { first = 0; break; }
+        is_first[b * S_max + k] = first;
+    }
+}
+
+// slab[b][t][s] = lp[t, b, ext_label(s)]
+__global__ __launch_bounds__(256) void ctc_gather_kernel(const float* __restrict__ lp, const int32_t* __restrict__ targets,
+                                                          const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
+                                                          float* __restrict__ slab, CtcDims d) {
+    const int64_t t = blockIdx.x, b = blockIdx.y;
+    if (t >= ilen[b]) return;
+    const int L = 2 * tlen[b] + 1;
+    const float* row = lp + t * d.lp_st + b * d.lp_sb;
+    const int32_t* tg = targets + b * d.S_max;
+    float* out = slab + (b * d.T_max + t) * d.L_max;
+    for (int s = threadIdx.x; s < L; s += blockDim.x) out[s] = row[(s & 1) ? tg[s >> 1] : d.blank];
+}
+
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    return logf(expf(a - m) + expf(b - m) + expf(c - m)) + m;
+}
+
+// Forward scan: alpha[b][t][s]; nll[b].  One workgroup per sample, ITEMS lattice positions per thread.
+template <int ITEMS>
+__global__ __launch_bounds__(SCAN_T) void ctc_alpha_kernel(const float* __restrict__ slab, const int32_t* __restrict__ targets,
+                                                            const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
+                                                            float* __restrict__ alpha, float* __restrict__ nll, CtcDims d) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];  // 2 * L_max
+    const int64_t b = blockIdx.x;
+    const int T = ilen[b], S = tlen[b], L = 2 * S + 1;
+    const int32_t* tg = targets + b * d.S_max;
+    const float* sl = slab + b * d.T_max * d.L_max;
+    float* al = alpha + b * d.T_max * d.L_max;
+    float* prev = rows;
+    float* cur = rows + d.L_max;
+    bool skip[ITEMS];
+    float ring[ITEMS][PD];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int s = threadIdx.x + j * SCAN_T;
+        skip[j] = (s < L) && (s & 1) && s >= 3 && tg[s >> 1] != tg[(s >> 1) - 1];
+        float v = -INFINITY;
+        if (s < L && T > 0) {
+            if (s == 0) v = sl[0];
+            else if (s == 1) v = sl[1];
+            al[s] = v;
+            prev[s] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < PD; ++u) ring[j][u] = (s < L && 1 + u < T) ? sl[(int64_t)(1 + u) * d.L_max + s] : 0.f;
+    }
+    __syncthreads();
+    for (int t0 = 1; t0 < T; t0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int t = t0 + u;
+            if (t < T) {  // uniform across the workgroup
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) {
+                    const int s = threadIdx.x + j * SCAN_T;
+                    const float lpv = ring[j][u];
+                    const int tn = t + PD;
+                    ring[j][u] = (s < L && tn < T) ? sl[(int64_t)tn * d.L_max + s] : 0.f;
+                    if (s < L) {
+                        const float a = prev[s];
+                        const float bb = s >= 1 ? prev[s - 1] : -INFINITY;
+                        const float c = skip[j] ? prev[s - 2] : -INFINITY;
+                        const float v = lse3(a, bb, c) + lpv;
+                        cur[s] = v;
+                        al[(int64_t)t * d.L_max + s] = v;
+                    }
+                }
+                __syncthreads();
+                float* tmp = prev; prev = cur; cur = tmp;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        float r = INFINITY;
+        if (T > 0) {
+            const float l1 = prev[L - 1];
+            const float l2 = L >= 2 ? prev[L - 2] : -INFINITY;
+            const float m = fmaxf(l1, l2);
+            r = (m == -INFINITY) ? INFINITY : -(logf(expf(l1 - m) + expf(l2 - m)) + m);
+        }
+        nll[b] = r;
+    }
+}
+
+// Backward scan: beta recursion; overwrites alpha[b][t][s] with alpha + beta.
+template <int ITEMS>
+__global__ __launch_bounds__(SCAN_T) void ctc_beta_kernel(const float* __restrict__ slab, const int32_t* __restrict__ targets,
+                                                           const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
+                                                           float* __restrict__ alpha, CtcDims d) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];
+    const int64_t b = blockIdx.x;
+    const int T = ilen[b], S = tlen[b], L = 2 * S + 1;
+    if (T <= 0) return;
+    const int32_t* tg = targets + b * d.S_max;
+    const float* sl = slab + b * d.T_max * d.L_max;
+    float* al = alpha + b * d.T_max * d.L_max;
+    float* prev = rows;
+    float* cur = rows + d.L_max;
+    bool skip[ITEMS];
+    float ring[ITEMS][PD];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int s = threadIdx.x + j * SCAN_T;
+        skip[j] = (s + 2 < L) && (s & 1) && tg[s >> 1] != tg[(s >> 1) + 1];
+        if (s < L) {
+            float v = -INFINITY;
+            if (s == L - 1 || s == L - 2) v = sl[(int64_t)(T - 1) * d.L_max + s];
+            prev[s] = v;
+            al[(int64_t)(T - 1) * d.L_max + s] += v;
+        }
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int t = T - 2 - u;
+            ring[j][u] = (s < L && t >= 0) ? sl[(int64_t)t * d.L_max + s] : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int t0 = T - 2; t0 >= 0; t0 -= PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int t = t0 - u;
+            if (t >= 0) {
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) {
+                    const int s = threadIdx.x + j * SCAN_T;
+                    const float lpv = ring[j][u];
+                    const int tn = t - PD;
+                    ring[j][u] = (s < L && tn >= 0) ? sl[(int64_t)tn * d.L_max + s] : 0.f;
+                    if (s < L) {
+                        const float a = prev[s];
+                        const float bb = s + 1 < L ? prev[s + 1] : -INFINITY;
+                        const float c = skip[j] ? prev[s + 2] : -INFINITY;
+                        const float v = lse3(a, bb, c) + lpv;
+                        cur[s] = v;
+                        al[(int64_t)t * d.L_max + s] += v;
+                    }
+                }
+                __syncthreads();
+                float* tmp = prev; prev = cur; cur = tmp;
+            }
+        }
+    }
+}
+
+// grad[t, b, c] = (exp(lp) - exp(lcab[c] + nll - lp)) * g_b, lcab[c] = log sum_{s: label(s) = c} exp(alpha+beta)[t, s].
+// One workgroup per (t, b): all classes get exp(lp) * g, then the classes that occur in the target are corrected:
+// blank by a fixed-order block reduction over the even lattice positions, every other label by the thread that owns
+// its FIRST occurrence walking the next_same chain in increasing s (deterministic).
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ lp, const float* __restrict__ ab,
+                                                        const int32_t* __restrict__ targets, const int32_t* __restrict__ next_same,
+                                                        const int32_t* __restrict__ is_first, const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
+                                                        const float* __restrict__ nll, float* __restrict__ grad, int64_t g_st,
+                                                        int64_t g_sb, float grad_scale, int mean_reduction, CtcDims d) {
+    __shared__ float red[8];
+    const int64_t t = blockIdx.x, b = blockIdx.y;
+    const int T = ilen[b], S = tlen[b], L = 2 * S + 1;
+    float* gr = grad + t * g_st + b * g_sb;
+    if (t >= T) {  // padded frames get zero gradient
+        for (int c = threadIdx.x; c < d.C; c += blockDim.x) gr[c] = 0.f;
+        return;
+    }
+    float g = grad_scale;
+    if (mean_reduction) g = grad_scale / ((float)(S > 0 ? S : 1) * (float)d.B);
+    const float* row = lp + t * d.lp_st + b * d.lp_sb;
+    const float* abr = ab + (b * d.T_max + t) * d.L_max;
+    const int32_t* tg = targets + b * d.S_max;
+    const int32_t* nx = next_same + b * d.S_max;
+    const float nl = nll[b];
+    for (int c = threadIdx.x; c < d.C; c += blockDim.x) gr[c] = expf(row[c]) * g;
+    // blank: positions 0, 2, ..., 2S
+    float m = -INFINITY;
+    for (int k = threadIdx.x; k <= S; k += blockDim.x) m = fmaxf(m, abr[2 * k]);
+    m = dyn::block_max(m, red);
+    float sum = 0.f;
+    if (m != -INFINITY)
+        for (int k = threadIdx.x; k <= S; k += blockDim.x) sum += expf(abr[2 * k] - m);
+    sum = dyn::block_sum(sum, red);  // also orders the exp(lp)*g stores before the corrections below
+    if (threadIdx.x == 0) {
+        const float lpb = row[d.blank];
+        const float lcab = (m == -INFINITY) ? -INFINITY : logf(sum) + m;
+        gr[d.blank] = (expf(lpb) - expf(lcab + nl - lpb)) * g;
+    }
+    // labels: thread k handles target index k if it is the first occurrence of its label
+    for (int k = threadIdx.x; k < S; k += blockDim.x) {
+        if (!is_first[b * d.S_max + k]) continue;
+        const int c = tg[k];
+        float mm = -INFINITY;
+        for (int j = k; j >= 0; j = nx[j]) mm = fmaxf(mm, abr[2 * j + 1]);
+        float ss = 0.f;
+        if (mm != -INFINITY)
+            for (int j = k; j >= 0; j = nx[j]) ss += expf(abr[2 * j + 1] - mm);
+        const float lcab = (mm == -INFINITY) ? -INFINITY : logf(ss) + mm;
+        const float lpc = row[c];
+        gr[c] = (expf(lpc) - expf(lcab + nl - lpc)) * g;
+    }
+}
+
+__global__ void ctc_loss_reduce_kernel(const float* __restrict__ nll, const int32_t* __restrict__ tlen, float* loss, int64_t B,
+                                       int mean_reduction) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float s = 0.f;
+    for (int64_t b = 0; b < B; ++b) {
+        const int S = tlen[b];
+        s += mean_reduction ? nll[b] / (float)(S > 0 ? S : 1) : nll[b];
+    }
+    *loss = mean_reduction ? s / (float)B : s;
+}
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct CtcWs {
+    float* slab; float* alpha; float* nll; int32_t* next_same; int32_t* is_first;
+    int64_t total;
+};
+
+CtcWs carve(void* ws, int64_t T, int64_t B, int64_t S_max) {
+    const int64_t L = 2 * S_max + 1;
+    CtcWs w;
+    char* p = (char*)ws;
+    int64_t off = 0;
+    w.slab = (float*)(p + off); off += align_up(B * T * L * 4, 256);
+    w.alpha = (float*)(p + off); off += align_up(B * T * L * 4, 256);
+    w.nll = (float*)(p + off); off += align_up(B * 4, 256);
+    w.next_same = (int32_t*)(p + off); off += align_up((B * S_max + 1) * 4, 256);
+    w.is_first = (int32_t*)(p + off); off += align_up((B * S_max + 1) * 4, 256);
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" int dyn_ctc_greedy(const float* log_probs, int64_t B, int64_t T, int64_t C, int64_t ld, int32_t blank,
+                              int32_t* argmax_ids, int32_t* out_ids, int32_t* out_len, void* stream) {
+    DYN_REQUIRE(log_probs && argmax_ids && out_ids && out_len && B >= 0 && T >= 0 && C > 0 && ld >= C, DYN_E_ARG,
+                "dyn_ctc_greedy: bad arguments");
+    if (B == 0) return DYN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (T > 0) {
+        int64_t g = dyn::cdiv(B * T, 4);
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, log_probs, argmax_ids, B * T, (int)C, ld);
+    }
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3((unsigned)B), dim3(1024), 0, st, argmax_ids, out_ids, out_len, T, T, (int)blank);
+    return dyn::check_launch("dyn_ctc_greedy");
+}
+
+extern "C" int64_t dyn_ctc_loss_workspace_bytes(int64_t T, int64_t B, int64_t S_max) {
+    return carve(nullptr, T, B, S_max > 0 ? S_max : 1).total;
+}
+
+extern "C" int dyn_ctc_loss(const float* log_probs, int64_t T, int64_t B, int64_t C, int64_t lp_stride_t, int64_t lp_stride_b,
+                            const int32_t* targets, int64_t S_max, const int32_t* input_lengths, const int32_t* target_lengths,
+                            int32_t blank, int32_t reduction, float grad_scale, float* loss, float* nll_per_sample,
+                            float* grad, int64_t g_stride_t, int64_t g_stride_b, void* workspace, int64_t workspace_bytes,
+                            void* stream) {
+    DYN_REQUIRE(log_probs && targets && input_lengths && target_lengths && loss && T > 0 && B > 0 && C > 0 && S_max >= 0 &&
+                    blank >= 0 && blank < C && (reduction == 0 || reduction == 1),
+                DYN_E_ARG, "dyn_ctc_loss: bad arguments");
+    const int64_t Sm = S_max > 0 ? S_max : 1;
+    const int64_t L = 2 * Sm + 1;
+    DYN_REQUIRE(L <= 8 * SCAN_T, DYN_E_UNSUPPORTED, "dyn_ctc_loss: lattice width %lld > %d unsupported", (long long)L, 8 * SCAN_T);
+    CtcWs w = carve(workspace, T, B, Sm);
+    DYN_REQUIRE(workspace && workspace_bytes >= w.total, DYN_E_WORKSPACE, "dyn_ctc_loss: workspace %lld < %lld bytes",
+                (long long)workspace_bytes, (long long)w.total);
+    CtcDims d;
+    d.T_max = T; d.B = B; d.C = C; d.lp_st = lp_stride_t; d.lp_sb = lp_stride_b; d.S_max = Sm; d.L_max = L; d.blank = blank;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ctc_prep_kernel, dim3((unsigned)B), dim3(256), 0, st, targets, target_lengths, w.next_same, w.is_first, Sm);
+    hipLaunchKernelGGL(ctc_gather_kernel, dim3((unsigned)T, (unsigned)B), dim3(256), 0, st, log_probs, targets, input_lengths,
+                       target_lengths, w.slab, d);
+    const int items = (int)dyn::cdiv(L, SCAN_T);
+    const size_t shm = (size_t)2 * L * sizeof(float);
+#define GO_A(I) hipLaunchKernelGGL((ctc_alpha_kernel<I>), dim3((unsigned)B), dim3(SCAN_T), shm, st, w.slab, targets, input_lengths, target_lengths, w.alpha, w.nll, d)
+#define GO_B(I) hipLaunchKernelGGL((ctc_beta_kernel<I>), dim3((unsigned)B), dim3(SCAN_T), shm, st, w.slab, targets, input_lengths, target_lengths, w.alpha, d)
+    if (items <= 1) GO_A(1); else if (items <= 2) GO_A(2); else if (items <= 4) GO_A(4); else GO_A(8);
+    hipLaunchKernelGGL(ctc_loss_reduce_kernel, dim3(1), dim3(64), 0, st, w.nll, target_lengths, loss, B, (int)reduction);
+    if (nll_per_sample) {
+        hipError_t e = hipMemcpyAsync(nll_per_sample, w.nll, B * sizeof(float), hipMemcpyDeviceToDevice, st);
+        DYN_REQUIRE(e == hipSuccess, DYN_E_LAUNCH, "dyn_ctc_loss: copy of per-sample nll failed");
+    }
+    if (grad) {
+        if (items <= 1) GO_B(1); else if (items <= 2) GO_B(2); else if (items <= 4) GO_B(4); else GO_B(8);
+        hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)T, (unsigned)B), dim3(256), 0, st, log_probs, w.alpha, targets,
+                           w.next_same, w.is_first, input_lengths, target_lengths, w.nll, grad, g_stride_t, g_stride_b, grad_scale,
+                           (int)reduction, d);
+    }
+#undef GO_A
+#undef GO_B
+    return dyn::check_launch("dyn_ctc_loss");
+}

@@ -1,0 +1,229 @@
+// LayerNorm / RMSNorm forward + backward over the channel dim (rows x C, C % 256 == 0, C <= 2048).
+// One wave64 per row: 16-B loads, the row lives in registers, mean / variance / gradient dot-products are
+// wavefront reductions (no LDS, no barrier on the forward path).  Weight gradients are accumulated per
+// workgroup in registers, written as partial rows and summed in a fixed order (deterministic).
+// Reference call sites: every LayerNorm / conv-module norm inside model(audio_signal=...) and its backward
+// (reference lcasr/lib.py:550,579); `default_norm: layer_norm` (earnings_finetune/lcasr160rb1.yaml:24).
+#include "common.h"
+
+namespace {
+
+constexpr int WPB = 4;  // waves (rows in flight) per workgroup
+
+// NV = C / 256 float4 per lane.
+template <int NV, bool RMS>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                        int64_t rows, float eps) {
+    constexpr int C = NV * 256;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float4 g[NV], b[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        g[j] = reinterpret_cast<const float4*>(gamma)[lane + 64 * j];
+        b[j] = (!RMS && beta) ? reinterpret_cast<const float4*>(beta)[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * WPB + w; row < rows; row += (int64_t)gridDim.x * WPB) {
+        float4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j] = reinterpret_cast<const float4*>(x + row * C)[lane + 64 * j];
+            s += RMS ? (v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w)
+                     : (v[j].x + v[j].y + v[j].z + v[j].w);
+        }
+        s = dyn::wave_sum(s);
+        float mean = 0.f, var;
+        if (RMS) {
+            var = s / C;
+        } else {
+            mean = s / C;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+                q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+            }
+            var = dyn::wave_sum(q) / C;
+        }
+        const float rstd = rsqrtf(var + eps);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float4 o;
+            o.x = (v[j].x - mean) * rstd * g[j].x + b[j].x;
+            o.y = (v[j].y - mean) * rstd * g[j].y + b[j].y;
+            o.z = (v[j].z - mean) * rstd * g[j].z + b[j].z;
+            o.w = (v[j].w - mean) * rstd * g[j].w + b[j].w;
+            reinterpret_cast<float4*>(y + row * C)[lane + 64 * j] = o;
+        }
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
+    }
+}
+
+// dx (+)= norm_bwd(dy);  partial_g/partial_b [gridDim.x, C] get this workgroup's weight-gradient sums.
+template <int NV, bool RMS>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                        const float* __restrict__ dy, float* dx, float dx_beta,
+                                                        float* __restrict__ partial_g, float* __restrict__ partial_b,
+                                                        int64_t rows) {
+    constexpr int C = NV * 256;
+    __shared__ float4 red[WPB][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float4 g[NV], ag[NV], ab[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        g[j] = reinterpret_cast<const float4*>(gamma)[lane + 64 * j];
+        ag[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * WPB + w; row < rows; row += (int64_t)gridDim.x * WPB) {
+        const float mean = RMS ? 0.f : mean_in[row];
+        const float rstd = rstd_in[row];
+        float4 xh[NV], gy[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float4 v = reinterpret_cast<const float4*>(x + row * C)[lane + 64 * j];
+            const float4 d = reinterpret_cast<const float4*>(dy + row * C)[lane + 64 * j];
+            xh[j].x = (v.x - mean) * rstd; xh[j].y = (v.y - mean) * rstd;
+            xh[j].z = (v.z - mean) * rstd; xh[j].w = (v.w - mean) * rstd;
+            ag[j].x += d.x * xh[j].x; ag[j].y += d.y * xh[j].y; ag[j].z += d.z * xh[j].z; ag[j].w += d.w * xh[j].w;
+            ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
+            gy[j].x = d.x * g[j].x; gy[j].y = d.y * g[j].y; gy[j].z = d.z * g[j].z; gy[j].w = d.w * g[j].w;
+            s1 += gy[j].x + gy[j].y + gy[j].z + gy[j].w;
+            s2 += gy[j].x * xh[j].x + gy[j].y * xh[j].y + gy[j].z * xh[j].z + gy[j].w * xh[j].w;
+        }
+        s2 = dyn::wave_sum(s2) / C;
+        s1 = RMS ? 0.f : dyn::wave_sum(s1) / C;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float4 o;
+            o.x = rstd * (gy[j].x - s1 - xh[j].x * s2);
+            o.y = rstd * (gy[j].y - s1 - xh[j].y * s2);
+            o.z = rstd * (gy[j].z - s1 - xh[j].z * s2);
+            o.w = rstd * (gy[j].w - s1 - xh[j].w * s2);
+            float4* p = reinterpret_cast<float4*>(dx + row * C) + lane + 64 * j;
+            if (dx_beta != 0.f) {
+                const float4 old = *p;
+                o.x += dx_beta * old.x; o.y += dx_beta * old.y; o.z += dx_beta * old.z; o.w += dx_beta * old.w;
+            }
+            *p = o;
+        }
+    }
+    // Combine the 4 waves' weight-gradient sums in wave order, then write this workgroup's partial row.
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        for (int pass = 0; pass < (RMS ? 1 : 2); ++pass) {
+            __syncthreads();
+            red[w][lane] = pass == 0 ? ag[j] : ab[j];
+            __syncthreads();
+            if (w == 0) {
+                float4 t = red[0][lane];
+#pragma unroll
+                for (int k = 1; k < WPB; ++k) { t.x += red[k][lane].x; t.y += red[k][lane].y; t.z += red[k][lane].z; t.w += red[k][lane].w; }
+                float* dst = (pass == 0 ? partial_g : partial_b) + (int64_t)blockIdx.x * C;
+                reinterpret_cast<float4*>(dst)[lane + 64 * j] = t;
+            }
+        }
+    }
+}
+
+__global__ void reduce_rows_kernel(const float* __restrict__ partial, float* out, int64_t P, int64_t n, float beta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int64_t p = 0; p < P; ++p) s += partial[p * n + i];
+        out[i] = (beta != 0.f ? beta * out[i] : 0.f) + s;
+    }
+}
+
+inline int bwd_blocks(int64_t rows) {
+    int64_t g = dyn::cdiv(rows, WPB);
+    if (g > 256) g = 256;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <bool RMS>
+int launch_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows,
+               int64_t C, float eps, hipStream_t st) {
+    int64_t gq = dyn::cdiv(rows, WPB);
+    if (gq > 2048) gq = 2048;
+    dim3 grid((unsigned)gq), blk(256);
+    switch (C / 256) {
+        case 1: hipLaunchKernelGGL((norm_fwd_kernel<1, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps); break;
+        case 2: hipLaunchKernelGGL((norm_fwd_kernel<2, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps); break;
+        case 3: hipLaunchKernelGGL((norm_fwd_kernel<3, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps); break;
+        case 4: hipLaunchKernelGGL((norm_fwd_kernel<4, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps); break;
+        case 8: hipLaunchKernelGGL((norm_fwd_kernel<8, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps); break;
+        default: dyn::set_error("norm: unsupported C=%lld (need C in {256,512,768,1024,2048})", (long long)C); return DYN_E_UNSUPPORTED;
+    }
+    return dyn::check_launch("dyn_norm_fwd");
+}
+
+template <bool RMS>
+int launch_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
+               float dx_beta, float* dgamma, float* dbeta, float wbeta, int64_t rows, int64_t C, void* ws, int64_t ws_bytes,
+               hipStream_t st) {
+    const int nb = bwd_blocks(rows);
+    DYN_REQUIRE(ws && ws_bytes >= (int64_t)2 * nb * C * (int64_t)sizeof(float), DYN_E_WORKSPACE, "norm_bwd: workspace too small");
+    float* pg = (float*)ws;
+    float* pb = pg + (int64_t)nb * C;
+    dim3 grid(nb), blk(256);
+    switch (C / 256) {
+        case 1: hipLaunchKernelGGL((norm_bwd_kernel<1, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows); break;
+        case 2: hipLaunchKernelGGL((norm_bwd_kernel<2, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows); break;
+        case 3: hipLaunchKernelGGL((norm_bwd_kernel<3, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows); break;
+        case 4: hipLaunchKernelGGL((norm_bwd_kernel<4, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows); break;
+        case 8: hipLaunchKernelGGL((norm_bwd_kernel<8, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows); break;
+        default: dyn::set_error("norm: unsupported C=%lld", (long long)C); return DYN_E_UNSUPPORTED;
+    }
+    int64_t rg = dyn::cdiv(C, 256);
+    if (dgamma) hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rg), dim3(256), 0, st, pg, dgamma, (int64_t)nb, C, wbeta);
+    if (!RMS && dbeta) hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rg), dim3(256), 0, st, pb, dbeta, (int64_t)nb, C, wbeta);
+    return dyn::check_launch("dyn_norm_bwd");
+}
+
+}  // namespace
+
+extern "C" int64_t dyn_norm_bwd_workspace_bytes(int64_t rows, int64_t C) {
+    return (int64_t)2 * bwd_blocks(rows) * C * (int64_t)sizeof(float);
+}
+
+extern "C" int dyn_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                 int64_t rows, int64_t C, float eps, void* stream) {
+    DYN_REQUIRE(x && gamma && y && mean && rstd && rows >= 0 && C > 0 && C % 256 == 0, DYN_E_ARG,
+                "dyn_layernorm_fwd: bad arguments (C=%lld must be a multiple of 256)", (long long)C);
+    if (rows == 0) return DYN_OK;
+    return launch_fwd<false>(x, gamma, beta, y, mean, rstd, rows, C, eps, (hipStream_t)stream);
+}
+
+extern "C" int dyn_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy,
+                                 float* dx, float dx_beta, float* dgamma, float* dbeta, float wgrad_beta, int64_t rows,
+                                 int64_t C, void* workspace, int64_t workspace_bytes, void* stream) {
+    DYN_REQUIRE(x && gamma && mean && rstd && dy && dx && rows >= 0 && C > 0 && C % 256 == 0, DYN_E_ARG,
+                "dyn_layernorm_bwd: bad arguments");
+    if (rows == 0) return DYN_OK;
+    return launch_bwd<false>(x, gamma, mean, rstd, dy, dx, dx_beta, dgamma, dbeta, wgrad_beta, rows, C, workspace,
+                             workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int dyn_rmsnorm_fwd(const float* x, const float* gamma, float* y, float* rstd, int64_t rows, int64_t C, float eps,
+                               void* stream) {
+    DYN_REQUIRE(x && gamma && y && rstd && rows >= 0 && C > 0 && C % 256 == 0, DYN_E_ARG, "dyn_rmsnorm_fwd: bad arguments");
+    if (rows == 0) return DYN_OK;
+    return launch_fwd<true>(x, gamma, nullptr, y, nullptr, rstd, rows, C, eps, (hipStream_t)stream);
+}
+
+extern "C" int dyn_rmsnorm_bwd(const float* x, const float* gamma, const float* rstd, const float* dy, float* dx,
+                               float dx_beta, float* dgamma, float wgrad_beta, int64_t rows, int64_t C, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    DYN_REQUIRE(x && gamma && rstd && dy && dx && rows >= 0 && C > 0 && C % 256 == 0, DYN_E_ARG, "dyn_rmsnorm_bwd: bad arguments");
+    if (rows == 0) return DYN_OK;
+    return launch_bwd<true>(x, gamma, nullptr, rstd, dy, dx, dx_beta, dgamma, nullptr, wgrad_beta, rows, C, workspace,
+                            workspace_bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,142 @@
+// Row softmax / log-softmax forward + backward (rows x L, any L <= 16384): one 256-thread workgroup per row,
+// the row is read ONCE into registers (ITEMS values per thread, coalesced stride-256 accesses), max and sum are
+// wavefront + LDS reductions, the result is written once: 1 read + 1 write of HBM per element.
+// Reference call sites: attention softmax and the CTC head's log_softmax inside model(audio_signal=...)
+// (reference lcasr/lib.py:550), `F.log_softmax` on wav2vec2 logits (reference wav2vec2/lib.py:169,417),
+// the self-conditioning softmax (yaml `self_conditioning: true`), and their backward passes (lib.py:579).
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+template <int ITEMS, bool LOG>
+__global__ __launch_bounds__(TPB) void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows,
+                                                           int L, int64_t ldx, int64_t ldy) {
+    __shared__ float red[8];
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* xr = x + row * ldx;
+        float v[ITEMS];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int c = threadIdx.x + j * TPB;
+            v[j] = c < L ? xr[c] : -INFINITY;
+            m = fmaxf(m, v[j]);
+        }
+        m = dyn::block_max(m, red);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int c = threadIdx.x + j * TPB;
+            const float e = c < L ? __expf(v[j] - m) : 0.f;
+            s += e;
+            if (!LOG) v[j] = e;
+        }
+        s = dyn::block_sum(s, red);
+        float* yr = y + row * ldy;
+        if (LOG) {
+            const float lse = m + __logf(s);
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int c = threadIdx.x + j * TPB;
+                if (c < L) yr[c] = v[j] - lse;
+            }
+        } else {
+            const float inv = 1.f / s;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int c = threadIdx.x + j * TPB;
+                if (c < L) yr[c] = v[j] * inv;
+            }
+        }
+    }
+}
+
+// softmax:      dx = y * (dy - sum(dy * y)) * scale
+// log_softmax:  dx = dy - exp(y) * sum(dy)
+template <int ITEMS, bool LOG>
+__global__ __launch_bounds__(TPB) void softmax_bwd_kernel(const float* __restrict__ y, const float* dy, float* dx,
+                                                           int64_t rows, int L, int64_t ld, float scale) {
+    __shared__ float red[8];
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* yr = y + row * ld;
+        const float* gr = dy + row * ld;
+        float yv[ITEMS], gv[ITEMS];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int c = threadIdx.x + j * TPB;
+            yv[j] = c < L ? yr[c] : 0.f;
+            gv[j] = c < L ? gr[c] : 0.f;
+            s += LOG ? gv[j] : gv[j] * yv[j];
+        }
+        s = dyn::block_sum(s, red);
+        float* xr = dx + row * ld;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int c = threadIdx.x + j * TPB;
+            if (c < L) xr[c] = LOG ? (gv[j] - __expf(yv[j]) * s) : (yv[j] * (gv[j] - s) * scale);
+        }
+    }
+}
+
+template <bool LOG>
+int launch_fwd(const float* x, float* y, int64_t rows, int64_t L, int64_t ldx, int64_t ldy, hipStream_t st) {
+    int64_t g = rows < 65535 * 4 ? rows : 65535 * 4;
+    dim3 grid((unsigned)g), blk(TPB);
+    const int items = (int)dyn::cdiv(L, TPB);
+#define GO(I) hipLaunchKernelGGL((softmax_fwd_kernel<I, LOG>), grid, blk, 0, st, x, y, rows, (int)L, ldx, ldy)
+    if (items <= 1) GO(1);
+    else if (items <= 2) GO(2);
+    else if (items <= 4) GO(4);
+    else if (items <= 8) GO(8);
+    else if (items <= 16) GO(16);
+    else if (items <= 32) GO(32);
+    else if (items <= 64) GO(64);
+    else { dyn::set_error("softmax: row length %lld > 16384 unsupported", (long long)L); return DYN_E_UNSUPPORTED; }
+#undef GO
+    return dyn::check_launch("dyn_softmax_fwd");
+}
+
+template <bool LOG>
+int launch_bwd(const float* y, const float* dy, float* dx, int64_t rows, int64_t L, int64_t ld, float scale, hipStream_t st) {
+    int64_t g = rows < 65535 * 4 ? rows : 65535 * 4;
+    dim3 grid((unsigned)g), blk(TPB);
+    const int items = (int)dyn::cdiv(L, TPB);
+#define GO(I) hipLaunchKernelGGL((softmax_bwd_kernel<I, LOG>), grid, blk, 0, st, y, dy, dx, rows, (int)L, ld, scale)
+    if (items <= 1) GO(1);
+    else if (items <= 2) GO(2);
+    else if (items <= 4) GO(4);
+    else if (items <= 8) GO(8);
+    else if (items <= 16) GO(16);
+    else if (items <= 32) GO(32);
+    else { dyn::set_error("softmax_bwd: row length %lld > 8192 unsupported", (long long)L); return DYN_E_UNSUPPORTED; }
+#undef GO
+    return dyn::check_launch("dyn_softmax_bwd");
+}
+
+}  // namespace
+
+extern "C" int dyn_softmax_fwd(const float* x, float* y, int64_t rows, int64_t L, int64_t ldx, int64_t ldy, void* stream) {
+    DYN_REQUIRE(x && y && rows >= 0 && L > 0 && ldx >= L && ldy >= L, DYN_E_ARG, "dyn_softmax_fwd: bad arguments");
+    if (rows == 0) return DYN_OK;
+    return launch_fwd<false>(x, y, rows, L, ldx, ldy, (hipStream_t)stream);
+}
+extern "C" int dyn_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int64_t L, int64_t ld, float scale,
+                               void* stream) {
+    DYN_REQUIRE(y && dy && dx && rows >= 0 && L > 0 && ld >= L, DYN_E_ARG, "dyn_softmax_bwd: bad arguments");
+    if (rows == 0) return DYN_OK;
+    return launch_bwd<false>(y, dy, dx, rows, L, ld, scale, (hipStream_t)stream);
+}
+extern "C" int dyn_log_softmax_fwd(const float* x, float* y, int64_t rows, int64_t L, int64_t ldx, int64_t ldy, void* stream) {
+    DYN_REQUIRE(x && y && rows >= 0 && L > 0 && ldx >= L && ldy >= L, DYN_E_ARG, "dyn_log_softmax_fwd: bad arguments");
+    if (rows == 0) return DYN_OK;
+    return launch_fwd<true>(x, y, rows, L, ldx, ldy, (hipStream_t)stream);
+}
+extern "C" int dyn_log_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int64_t L, int64_t ld,
+                                   void* stream) {
+    DYN_REQUIRE(y && dy && dx && rows >= 0 && L > 0 && ld >= L, DYN_E_ARG, "dyn_log_softmax_bwd: bad arguments");
+    if (rows == 0) return DYN_OK;
+    return launch_bwd<true>(y, dy, dx, rows, L, ld, 1.f, (hipStream_t)stream);
+}

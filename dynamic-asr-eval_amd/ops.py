@@ -1,46 +1,54 @@
 """Thin tensor-level wrappers over the C-ABI (include/dyneval.h).
 
 PyTorch is plumbing here: it owns device memory and the stream; every arithmetic op on the product path is a
-hand-written HIP kernel reached through ctypes.  Wrappers validate device/dtype/contiguity on the host so a
-kernel never sees a shape it does not expect."""
+hand-written HIP kernel reached through ctypes.  Wrappers validate device/dtype/contiguity/alignment on the host so
+a kernel never sees a shape it does not expect.  There is no CPU fallback: a CPU tensor raises DynError."""
 import ctypes
 
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, check
+from ._lib import DynError, GemmDesc, check
 
 _WS = {}
-WORKSPACE_BYTES = 768 << 20
+WORKSPACE_BYTES = 1 << 30
+F32 = torch.float32
+I32 = torch.int32
+
+
+def _L():
+    return _lib.load()
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch.cuda.current_stream().cuda_stream
 
 
-def _chk(t, name, dtype=torch.float32):
+def _chk(t, name, dtype=F32):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
-        raise _lib.DynError(f"{name}: expected a CUDA tensor (the HIP path has no CPU fallback)")
+        raise DynError(f"{name}: expected a CUDA tensor (the HIP path has no CPU fallback)")
     if t.dtype != dtype:
-        raise _lib.DynError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+        raise DynError(f"{name}: expected dtype {dtype}, got {t.dtype}")
     return t
 
 
-def _cc(t, name, dtype=torch.float32):
+def _cc(t, name, dtype=F32):
     _chk(t, name, dtype)
     if not t.is_contiguous():
-        raise _lib.DynError(f"{name}: expected a contiguous tensor")
+        raise DynError(f"{name}: expected a contiguous tensor")
+    if t.data_ptr() % 16:
+        raise DynError(f"{name}: expected a 16-byte aligned tensor")
     return t
 
 
-def _p(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+def _opt(t, name, dtype=F32):
+    return 0 if t is None else _cc(t, name, dtype).data_ptr()
 
 
 def workspace(device=None):
-    """One caller-owned scratch buffer per device (split-K slabs, partial reductions)."""
+    """One caller-owned scratch buffer per device (split-K slabs, partial reductions, CTC lattice)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
@@ -48,6 +56,7 @@ def workspace(device=None):
     return ws
 
 
+# ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
          nb1=1, nb2=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, split_k=0):
     """Raw strided batched GEMM (see dyn_gemm_desc). Offsets are in elements from each tensor's data_ptr."""
@@ -64,35 +73,359 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha
     d.split_k = split_k
     ws = workspace(c.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-    check(_lib.load().dyn_gemm_f32(ctypes.byref(d), _stream()), "dyn_gemm_f32")
+    check(_L().dyn_gemm_f32(ctypes.byref(d), _stream()), "dyn_gemm_f32")
     return c
 
 
-def linear(x, w, bias=None, out=None):
-    """y[M, N] = x[M, K] @ w[N, K]^T + bias  (torch.nn.Linear layout)."""
+def linear(x, w, bias=None, out=None, alpha=1.0, beta=0.0):
+    """out[M, N] = alpha * x[M, K] @ w[N, K]^T + beta * out + bias   (torch.nn.Linear weight layout)."""
     _cc(x, "linear.x"); _cc(w, "linear.w")
     K = x.shape[-1]
     M = x.numel() // K
     N = w.shape[0]
-    assert w.shape[1] == K
+    assert w.shape[1] == K, (w.shape, K)
     if out is None:
-        out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
-    return gemm(x, w, out, trans_b=True, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias)
+        assert beta == 0.0
+        out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=F32)
+    return gemm(x, w, out, trans_b=True, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, alpha=alpha, beta=beta)
 
 
-def linear_dgrad(dy, w, out=None, beta=0.0):
-    """dx[M, K] = dy[M, N] @ w[N, K]."""
+def linear_dgrad(dy, w, out=None, alpha=1.0, beta=0.0):
+    """dx[M, K] = alpha * dy[M, N] @ w[N, K] + beta * dx."""
     _cc(dy, "linear_dgrad.dy"); _cc(w, "linear_dgrad.w")
     N, K = w.shape
     M = dy.numel() // N
     if out is None:
-        out = torch.empty(*dy.shape[:-1], K, device=dy.device, dtype=torch.float32)
-    return gemm(dy, w, out, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, beta=beta)
+        assert beta == 0.0
+        out = torch.empty(*dy.shape[:-1], K, device=dy.device, dtype=F32)
+    return gemm(dy, w, out, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, alpha=alpha, beta=beta)
 
 
-def linear_wgrad(dy, x, dw, beta=1.0):
-    """dw[N, K] (+)= dy[M, N]^T @ x[M, K]  (deterministic split-K)."""
+def linear_wgrad(dy, x, dw, alpha=1.0, beta=1.0):
+    """dw[N, K] = alpha * dy[M, N]^T @ x[M, K] + beta * dw   (deterministic split-K)."""
     _cc(dy, "linear_wgrad.dy"); _cc(x, "linear_wgrad.x"); _cc(dw, "linear_wgrad.dw")
     N, K = dw.shape
     M = dy.numel() // N
-    return gemm(dy, x, dw, trans_a=True, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, beta=beta)
+    return gemm(dy, x, dw, trans_a=True, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, alpha=alpha, beta=beta)
+
+
+# ----------------------------------------------------------------------------------------------- elementwise
+def silu(x, out=None):
+    _cc(x, "silu.x")
+    out = torch.empty_like(x) if out is None else _cc(out, "silu.out")
+    check(_L().dyn_silu_fwd(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "dyn_silu_fwd")
+    return out
+
+
+def silu_bwd(x, dy, out=None):
+    _cc(x, "silu_bwd.x"); _cc(dy, "silu_bwd.dy")
+    out = torch.empty_like(x) if out is None else _cc(out, "silu_bwd.out")
+    check(_L().dyn_silu_bwd(x.data_ptr(), dy.data_ptr(), out.data_ptr(), x.numel(), _stream()), "dyn_silu_bwd")
+    return out
+
+
+def glu(u, out=None):
+    _cc(u, "glu.u")
+    C = u.shape[-1] // 2
+    rows = u.numel() // (2 * C)
+    out = torch.empty(*u.shape[:-1], C, device=u.device, dtype=F32) if out is None else _cc(out, "glu.out")
+    check(_L().dyn_glu_fwd(u.data_ptr(), out.data_ptr(), rows, C, _stream()), "dyn_glu_fwd")
+    return out
+
+
+def glu_bwd(u, dy, out=None):
+    _cc(u, "glu_bwd.u"); _cc(dy, "glu_bwd.dy")
+    C = u.shape[-1] // 2
+    rows = u.numel() // (2 * C)
+    out = torch.empty_like(u) if out is None else _cc(out, "glu_bwd.out")
+    check(_L().dyn_glu_bwd(u.data_ptr(), dy.data_ptr(), out.data_ptr(), rows, C, _stream()), "dyn_glu_bwd")
+    return out
+
+
+def axpby(x, y, a=1.0, b=1.0):
+    """y = a * x + b * y (in place on y)."""
+    _cc(x, "axpby.x"); _cc(y, "axpby.y")
+    assert x.numel() == y.numel()
+    check(_L().dyn_axpby(x.data_ptr(), y.data_ptr(), a, b, x.numel(), _stream()), "dyn_axpby")
+    return y
+
+
+def colsum(x, out, beta=1.0):
+    """out[C] = beta * out + sum over rows of x[rows, C]."""
+    _cc(x, "colsum.x"); _cc(out, "colsum.out")
+    C = out.numel()
+    rows = x.numel() // C
+    ws = workspace(x.device)
+    check(_L().dyn_colsum(x.data_ptr(), out.data_ptr(), rows, C, beta, ws.data_ptr(), ws.numel(), _stream()), "dyn_colsum")
+    return out
+
+
+def transpose_ft(x, out=None):
+    """[F, T] window view (T contiguous, arbitrary row stride) -> contiguous [T, F]."""
+    _chk(x, "transpose_ft.x")
+    F, T = x.shape
+    assert x.stride(1) == 1
+    out = torch.empty(T, F, device=x.device, dtype=F32) if out is None else _cc(out, "transpose_ft.out")
+    check(_L().dyn_transpose_ft(x.data_ptr(), out.data_ptr(), F, T, x.stride(0), _stream()), "dyn_transpose_ft")
+    return out
+
+
+def specaug_freqmask(x, f0, width, value=0.0):
+    """In-place frequency masks on a contiguous [F, T] window; f0/width are int32 CUDA tensors."""
+    _cc(x, "specaug.x"); _cc(f0, "specaug.f0", I32); _cc(width, "specaug.width", I32)
+    F, T = x.shape
+    check(_L().dyn_specaug_freqmask(x.data_ptr(), F, T, f0.data_ptr(), width.data_ptr(), f0.numel(), value, _stream()),
+          "dyn_specaug_freqmask")
+    return x
+
+
+# ----------------------------------------------------------------------------------------------- norms
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    _cc(x, "layernorm.x"); _cc(gamma, "layernorm.gamma")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    out = torch.empty_like(x) if out is None else _cc(out, "layernorm.out")
+    mean = torch.empty(rows, device=x.device, dtype=F32)
+    rstd = torch.empty(rows, device=x.device, dtype=F32)
+    check(_L().dyn_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), _opt(beta, "layernorm.beta"), out.data_ptr(),
+                                 mean.data_ptr(), rstd.data_ptr(), rows, C, eps, _stream()), "dyn_layernorm_fwd")
+    return out, mean, rstd
+
+
+def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, dx_beta=0.0, wgrad_beta=1.0):
+    _cc(x, "layernorm_bwd.x"); _cc(dy, "layernorm_bwd.dy"); _cc(dx, "layernorm_bwd.dx")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    ws = workspace(x.device)
+    check(_L().dyn_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(),
+                                 dx.data_ptr(), dx_beta, _opt(dgamma, "dgamma"), _opt(dbeta, "dbeta"), wgrad_beta, rows, C,
+                                 ws.data_ptr(), ws.numel(), _stream()), "dyn_layernorm_bwd")
+    return dx
+
+
+def rmsnorm(x, gamma, eps=1e-5, out=None):
+    _cc(x, "rmsnorm.x"); _cc(gamma, "rmsnorm.gamma")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    out = torch.empty_like(x) if out is None else _cc(out, "rmsnorm.out")
+    rstd = torch.empty(rows, device=x.device, dtype=F32)
+    check(_L().dyn_rmsnorm_fwd(x.data_ptr(), gamma.data_ptr(), out.data_ptr(), rstd.data_ptr(), rows, C, eps, _stream()),
+          "dyn_rmsnorm_fwd")
+    return out, rstd
+
+
+def rmsnorm_bwd(x, gamma, rstd, dy, dx, dgamma, dx_beta=0.0, wgrad_beta=1.0):
+    _cc(x, "rmsnorm_bwd.x"); _cc(dy, "rmsnorm_bwd.dy"); _cc(dx, "rmsnorm_bwd.dx")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    ws = workspace(x.device)
+    check(_L().dyn_rmsnorm_bwd(x.data_ptr(), gamma.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(), dx_beta,
+                               _opt(dgamma, "dgamma"), wgrad_beta, rows, C, ws.data_ptr(), ws.numel(), _stream()),
+          "dyn_rmsnorm_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------- softmax
+def _rows_L(x):
+    L = x.shape[-1]
+    return x.numel() // L, L
+
+
+def softmax(x, out=None):
+    _cc(x, "softmax.x")
+    rows, L = _rows_L(x)
+    out = torch.empty_like(x) if out is None else _cc(out, "softmax.out")
+    check(_L().dyn_softmax_fwd(x.data_ptr(), out.data_ptr(), rows, L, L, L, _stream()), "dyn_softmax_fwd")
+    return out
+
+
+def softmax_bwd(y, dy, out=None, scale=1.0):
+    _cc(y, "softmax_bwd.y"); _cc(dy, "softmax_bwd.dy")
+    rows, L = _rows_L(y)
+    out = torch.empty_like(y) if out is None else _cc(out, "softmax_bwd.out")
+    check(_L().dyn_softmax_bwd(y.data_ptr(), dy.data_ptr(), out.data_ptr(), rows, L, L, scale, _stream()), "dyn_softmax_bwd")
+    return out
+
+
+def log_softmax(x, out=None):
+    _cc(x, "log_softmax.x")
+    rows, L = _rows_L(x)
+    out = torch.empty_like(x) if out is None else _cc(out, "log_softmax.out")
+    check(_L().dyn_log_softmax_fwd(x.data_ptr(), out.data_ptr(), rows, L, L, L, _stream()), "dyn_log_softmax_fwd")
+    return out
+
+
+def log_softmax_bwd(y, dy, out=None):
+    _cc(y, "log_softmax_bwd.y"); _cc(dy, "log_softmax_bwd.dy")
+    rows, L = _rows_L(y)
+    out = torch.empty_like(y) if out is None else _cc(out, "log_softmax_bwd.out")
+    check(_L().dyn_log_softmax_bwd(y.data_ptr(), dy.data_ptr(), out.data_ptr(), rows, L, L, _stream()), "dyn_log_softmax_bwd")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- convolutions
+def dwconv1d(x, w, bias, out=None):
+    """x [B, T, C] channels-last, w [C, KW]."""
+    _cc(x, "dwconv1d.x"); _cc(w, "dwconv1d.w")
+    B, T, C = x.shape
+    out = torch.empty_like(x) if out is None else _cc(out, "dwconv1d.out")
+    check(_L().dyn_dwconv1d_fwd(x.data_ptr(), w.data_ptr(), _opt(bias, "bias"), out.data_ptr(), B, T, C, w.shape[1], _stream()),
+          "dyn_dwconv1d_fwd")
+    return out
+
+
+def dwconv1d_dgrad(dy, w, out=None, beta=0.0):
+    _cc(dy, "dwconv1d_dgrad.dy"); _cc(w, "dwconv1d_dgrad.w")
+    B, T, C = dy.shape
+    out = torch.empty_like(dy) if out is None else _cc(out, "dwconv1d_dgrad.out")
+    check(_L().dyn_dwconv1d_dgrad(dy.data_ptr(), w.data_ptr(), out.data_ptr(), B, T, C, w.shape[1], beta, _stream()),
+          "dyn_dwconv1d_dgrad")
+    return out
+
+
+def dwconv1d_wgrad(x, dy, dw, dbias, beta=1.0):
+    _cc(x, "dwconv1d_wgrad.x"); _cc(dy, "dwconv1d_wgrad.dy"); _cc(dw, "dwconv1d_wgrad.dw")
+    B, T, C = x.shape
+    ws = workspace(x.device)
+    check(_L().dyn_dwconv1d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _opt(dbias, "dbias"), beta, B, T, C,
+                                  dw.shape[1], ws.data_ptr(), ws.numel(), _stream()), "dyn_dwconv1d_wgrad")
+
+
+def out_len(n):
+    """Output length of a 3-wide, stride-2, pad-1 convolution."""
+    return (n - 1) // 2 + 1
+
+
+def conv2d_first(x, w, bias, out=None):
+    """x [B, T, F] -> z [B, To, Fo, C]; w [C, 3, 3]."""
+    _cc(x, "conv2d_first.x"); _cc(w, "conv2d_first.w"); _cc(bias, "conv2d_first.bias")
+    B, T, F = x.shape
+    C = w.shape[0]
+    if out is None:
+        out = torch.empty(B, out_len(T), out_len(F), C, device=x.device, dtype=F32)
+    check(_L().dyn_conv2d_first_fwd(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), B, T, F, C, _stream()),
+          "dyn_conv2d_first_fwd")
+    return out
+
+
+def conv2d_first_wgrad(x, dz, dw, dbias, beta=1.0):
+    _cc(x, "conv2d_first_wgrad.x"); _cc(dz, "conv2d_first_wgrad.dz")
+    B, T, F = x.shape
+    C = dw.shape[0]
+    ws = workspace(x.device)
+    check(_L().dyn_conv2d_first_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), dbias.data_ptr(), beta, B, T, F, C,
+                                      ws.data_ptr(), ws.numel(), _stream()), "dyn_conv2d_first_wgrad")
+
+
+def dwconv2d_s2(z, w, bias, out=None):
+    """u = bias + dw3x3_s2(silu(z)); z [B, T, F, C] -> [B, To, Fo, C]; w [C, 3, 3]."""
+    _cc(z, "dwconv2d_s2.z"); _cc(w, "dwconv2d_s2.w"); _cc(bias, "dwconv2d_s2.bias")
+    B, T, F, C = z.shape
+    if out is None:
+        out = torch.empty(B, out_len(T), out_len(F), C, device=z.device, dtype=F32)
+    check(_L().dyn_dwconv2d_s2_fwd(z.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), B, T, F, C, _stream()),
+          "dyn_dwconv2d_s2_fwd")
+    return out
+
+
+def dwconv2d_s2_dgrad(z, w, du, out=None):
+    _cc(z, "dwconv2d_s2_dgrad.z"); _cc(du, "dwconv2d_s2_dgrad.du")
+    B, T, F, C = z.shape
+    out = torch.empty_like(z) if out is None else _cc(out, "dwconv2d_s2_dgrad.out")
+    check(_L().dyn_dwconv2d_s2_dgrad(z.data_ptr(), w.data_ptr(), du.data_ptr(), out.data_ptr(), B, T, F, C, _stream()),
+          "dyn_dwconv2d_s2_dgrad")
+    return out
+
+
+def dwconv2d_s2_wgrad(z, du, dw, dbias, beta=1.0):
+    _cc(z, "dwconv2d_s2_wgrad.z"); _cc(du, "dwconv2d_s2_wgrad.du")
+    B, T, F, C = z.shape
+    ws = workspace(z.device)
+    check(_L().dyn_dwconv2d_s2_wgrad(z.data_ptr(), du.data_ptr(), dw.data_ptr(), dbias.data_ptr(), beta, B, T, F, C,
+                                     ws.data_ptr(), ws.numel(), _stream()), "dyn_dwconv2d_s2_wgrad")
+
+
+def rotary(x, cos, sin, B, T, n_heads, D, row_stride, inverse=False):
+    """In place on the first n_heads*D floats of every row_stride-float row of x."""
+    _cc(x, "rotary.x"); _cc(cos, "rotary.cos"); _cc(sin, "rotary.sin")
+    assert cos.shape[0] >= T and cos.shape[1] == D // 2
+    check(_L().dyn_rotary(x.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, T, n_heads, D, row_stride, int(inverse), _stream()),
+          "dyn_rotary")
+    return x
+
+
+# ----------------------------------------------------------------------------------------------- CTC
+def ctc_greedy(log_probs, blank):
+    """log_probs [B, T, C] (or [T, C]) on device -> (ids int32 [B, T] device, lengths int32 [B] device).
+    Only out_len[b] leading ids of each row are valid."""
+    _cc(log_probs, "ctc_greedy.log_probs")
+    lp = log_probs if log_probs.dim() == 3 else log_probs.unsqueeze(0)
+    B, T, C = lp.shape
+    arg = torch.empty(B, T, device=lp.device, dtype=I32)
+    ids = torch.empty(B, T, device=lp.device, dtype=I32)
+    n = torch.empty(B, device=lp.device, dtype=I32)
+    check(_L().dyn_ctc_greedy(lp.data_ptr(), B, T, C, C, blank, arg.data_ptr(), ids.data_ptr(), n.data_ptr(), _stream()),
+          "dyn_ctc_greedy")
+    return ids, n
+
+
+def ctc_loss(log_probs, targets, input_lengths, target_lengths, blank, reduction="sum", grad_scale=1.0, want_grad=True):
+    """log_probs [B, T, C] contiguous; targets int32 [B, S_max]; lengths int32 [B] (all on device).
+    Returns (loss [1] device tensor, nll [B], grad [B, T, C] or None) with torch.nn.CTCLoss semantics."""
+    _cc(log_probs, "ctc_loss.log_probs"); _cc(targets, "ctc_loss.targets", I32)
+    _cc(input_lengths, "ctc_loss.input_lengths", I32); _cc(target_lengths, "ctc_loss.target_lengths", I32)
+    B, T, C = log_probs.shape
+    S_max = targets.shape[1] if targets.numel() else 0
+    loss = torch.empty(1, device=log_probs.device, dtype=F32)
+    nll = torch.empty(B, device=log_probs.device, dtype=F32)
+    grad = torch.empty_like(log_probs) if want_grad else None
+    ws = workspace(log_probs.device)
+    need = _L().dyn_ctc_loss_workspace_bytes(T, B, S_max)
+    if need > ws.numel():
+        raise DynError(f"ctc_loss: workspace {ws.numel()} < {need} bytes")
+    tptr = targets.data_ptr() if targets.numel() else nll.data_ptr()
+    check(_L().dyn_ctc_loss(log_probs.data_ptr(), T, B, C, C, T * C, tptr, S_max, input_lengths.data_ptr(),
+                            target_lengths.data_ptr(), blank, {"sum": 0, "mean": 1}[reduction], grad_scale, loss.data_ptr(),
+                            nll.data_ptr(), 0 if grad is None else grad.data_ptr(), C, T * C, ws.data_ptr(), ws.numel(),
+                            _stream()), "dyn_ctc_loss")
+    return loss, nll, grad
+
+
+# ----------------------------------------------------------------------------------------------- optimiser / stitch
+def madgrad_step(p, g, s, nu, x0, lr, momentum, weight_decay, eps, step):
+    for t, n in ((p, "p"), (g, "g"), (s, "s"), (nu, "nu"), (x0, "x0")):
+        _cc(t, "madgrad." + n)
+    check(_L().dyn_madgrad_step(p.data_ptr(), g.data_ptr(), s.data_ptr(), nu.data_ptr(), x0.data_ptr(), p.numel(), lr, momentum,
+                                weight_decay, eps, step, _stream()), "dyn_madgrad_step")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _cc(t, "adam." + n)
+    check(_L().dyn_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                             weight_decay, step, _stream()), "dyn_adam_step")
+
+
+def clip_grad_norm(g, max_norm):
+    """In-place global-norm clip of a flat gradient buffer; returns a 2-float device tensor (norm, coefficient)."""
+    _cc(g, "clip_grad_norm.g")
+    out = torch.empty(2, device=g.device, dtype=F32)
+    ws = workspace(g.device)
+    check(_L().dyn_clip_grad_norm(g.data_ptr(), g.numel(), max_norm, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "dyn_clip_grad_norm")
+    return out
+
+
+def stitch_accumulate(log_probs, acc, count, pos):
+    _cc(log_probs, "stitch.log_probs"); _cc(acc, "stitch.acc"); _cc(count, "stitch.count")
+    rows, C = log_probs.shape
+    check(_L().dyn_stitch_accumulate(log_probs.data_ptr(), C, acc.data_ptr(), count.data_ptr(), pos, rows, C, acc.shape[0],
+                                     _stream()), "dyn_stitch_accumulate")
+
+
+def stitch_finalize(acc, count, rows):
+    _cc(acc, "stitch.acc"); _cc(count, "stitch.count")
+    C = acc.shape[1]
+    out = torch.empty(rows, C, device=acc.device, dtype=F32)
+    check(_L().dyn_stitch_finalize(acc.data_ptr(), count.data_ptr(), out.data_ptr(), rows, C, _stream()), "dyn_stitch_finalize")
+    return out

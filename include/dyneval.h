@@ -58,6 +58,127 @@ typedef struct {
 int64_t dyn_gemm_f32_workspace_bytes(const dyn_gemm_desc* d);
 int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * HBM-bound encoder pieces (activations, norms, softmax, convolutions).  All replace ops inside
+ * model(audio_signal=...) (reference lcasr/lib.py:550,603) and its autograd backward (lib.py:579);
+ * the architecture constants come from earnings_finetune/lcasr160rb1.yaml:1-29.
+ * "beta" arguments accumulate into the destination (dst = result + beta * dst), which is how residual
+ * gradients and repeated weight-gradient contributions are summed without extra passes.
+ * ------------------------------------------------------------------------------------------------ */
+int dyn_silu_fwd(const float* x, float* y, int64_t n, void* stream);
+int dyn_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* GLU over the last dim: u [rows, 2C] -> y [rows, C] = u[:, :C] * sigmoid(u[:, C:]) */
+int dyn_glu_fwd(const float* u, float* y, int64_t rows, int64_t C, void* stream);
+int dyn_glu_bwd(const float* u, const float* dy, float* du, int64_t rows, int64_t C, void* stream);
+/* y = a * x + b * y */
+int dyn_axpby(const float* x, float* y, float a, float b, int64_t n, void* stream);
+/* out[C] = beta * out + sum_rows x[rows, C]   (bias gradients; deterministic two-stage) */
+int64_t dyn_colsum_workspace_bytes(int64_t rows, int64_t C);
+int dyn_colsum(const float* x, float* out, int64_t rows, int64_t C, float beta, void* workspace, int64_t workspace_bytes,
+               void* stream);
+int dyn_reduce_partials(const float* partial, float* out, int64_t P, int64_t n, float beta, void* stream);
+/* [F, T] (row stride ldx) -> [T, F]: a log-mel window enters the encoder channels-last */
+int dyn_transpose_ft(const float* x, float* y, int64_t F, int64_t T, int64_t ldx, void* stream);
+
+/* LayerNorm / RMSNorm over C (C % 256 == 0, C <= 2048); mean/rstd [rows] are saved for the backward. */
+int64_t dyn_norm_bwd_workspace_bytes(int64_t rows, int64_t C);
+int dyn_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                      int64_t rows, int64_t C, float eps, void* stream);
+int dyn_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
+                      float dx_beta, float* dgamma, float* dbeta, float wgrad_beta, int64_t rows, int64_t C,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+int dyn_rmsnorm_fwd(const float* x, const float* gamma, float* y, float* rstd, int64_t rows, int64_t C, float eps,
+                    void* stream);
+int dyn_rmsnorm_bwd(const float* x, const float* gamma, const float* rstd, const float* dy, float* dx, float dx_beta,
+                    float* dgamma, float wgrad_beta, int64_t rows, int64_t C, void* workspace, int64_t workspace_bytes,
+                    void* stream);
+
+/* Row softmax / log-softmax (row length L <= 16384 fwd, <= 8192 bwd).  softmax_bwd: dx = y*(dy - sum(dy*y))*scale;
+ * log_softmax_bwd: dx = dy - exp(y)*sum(dy).  F.log_softmax call sites: reference wav2vec2/lib.py:169,417. */
+int dyn_softmax_fwd(const float* x, float* y, int64_t rows, int64_t L, int64_t ldx, int64_t ldy, void* stream);
+int dyn_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int64_t L, int64_t ld, float scale,
+                    void* stream);
+int dyn_log_softmax_fwd(const float* x, float* y, int64_t rows, int64_t L, int64_t ldx, int64_t ldy, void* stream);
+int dyn_log_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int64_t L, int64_t ld, void* stream);
+
+/* Depthwise Conv1d over time, channels-last x [B, T, C], w [C, KW], 'same' zero padding (conformer conv module,
+ * `conv_kernel_size: 9`, yaml:15).  KW in {3,5,7,9,15,31}. */
+int dyn_dwconv1d_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t T, int64_t C,
+                     int64_t KW, void* stream);
+int dyn_dwconv1d_dgrad(const float* dy, const float* w, float* dx, int64_t B, int64_t T, int64_t C, int64_t KW,
+                       float dx_beta, void* stream);
+int64_t dyn_dwconv1d_wgrad_workspace_bytes(int64_t B, int64_t T, int64_t C, int64_t KW);
+int dyn_dwconv1d_wgrad(const float* x, const float* dy, float* dw, float* dbias, float beta, int64_t B, int64_t T, int64_t C,
+                       int64_t KW, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* dw_striding x8 subsampling (`subsampling: dw_striding`, `subsampling_conv_channels: 256`, `subsampling_act: silu`,
+ * yaml:10-13), channels-last.  Output sizes: To = (T-1)/2+1, Fo = (F-1)/2+1 (3x3, stride 2, pad 1).
+ *   conv2d_first: x [B,T,F] (1 channel) -> z [B,To,Fo,C], w [C,3,3]
+ *   dwconv2d_s2 : u = bias + dw3x3_s2(silu(z)),  z [B,T,F,C] -> u [B,To,Fo,C]   (SiLU fused into the load)
+ * The 1x1 pointwise convs between them are dyn_gemm_f32 calls. */
+int dyn_conv2d_first_fwd(const float* x, const float* w, const float* bias, float* z, int64_t B, int64_t T, int64_t F,
+                         int64_t C, void* stream);
+int64_t dyn_conv2d_wgrad_workspace_bytes(int64_t B, int64_t To, int64_t C);
+int dyn_conv2d_first_wgrad(const float* x, const float* dz, float* dw, float* dbias, float beta, int64_t B, int64_t T,
+                           int64_t F, int64_t C, void* workspace, int64_t workspace_bytes, void* stream);
+int dyn_dwconv2d_s2_fwd(const float* z, const float* w, const float* bias, float* u, int64_t B, int64_t T, int64_t F,
+                        int64_t C, void* stream);
+int dyn_dwconv2d_s2_dgrad(const float* z, const float* w, const float* du, float* dz, int64_t B, int64_t T, int64_t F,
+                          int64_t C, void* stream);
+int dyn_dwconv2d_s2_wgrad(const float* z, const float* du, float* dw, float* dbias, float beta, int64_t B, int64_t T,
+                          int64_t F, int64_t C, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Rotary position embedding, in place on the first n_heads*D floats of each row of x ([B*T] rows of row_stride floats);
+ * cos/sin tables are [T, D/2]; inverse != 0 applies the transpose (the backward). yaml:22,28. */
+int dyn_rotary(float* x, const float* cos_table, const float* sin_table, int64_t B, int64_t T, int64_t n_heads, int64_t D,
+               int64_t row_stride, int32_t inverse, void* stream);
+
+/* SpecAugment frequency masks on a [F, T] log-mel window, in place: rows f0[k] <= f < f0[k]+width[k] := value.
+ * Replaces lcasr.utils.augmentation.SpecAugment as called at reference lcasr/lib.py:499,541 (mask positions are
+ * drawn on the host so the RNG stream stays the caller's). */
+int dyn_specaug_freqmask(float* x, int64_t F, int64_t T, const int32_t* f0, const int32_t* width, int64_t n_masks,
+                         float value, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CTC.  dyn_ctc_greedy replaces GreedyCTCDecoder on a CPU copy of the posteriors (reference lcasr/lib.py:498,
+ * 559,565; run_dynamic_eval_full.py:53,100): argmax over classes (first maximum), collapse repeats, drop `blank`.
+ *   log_probs [B*T rows, C] (row stride ld); argmax_ids [B*T]; out_ids [B, T] (prefix of out_len[b] valid ids).
+ * dyn_ctc_loss replaces torch.nn.CTCLoss(blank, reduction) forward + backward (reference lcasr/lib.py:492,575,579;
+ * wav2vec2/lib.py:351,434): log_probs[t, b, c] at t*lp_stride_t + b*lp_stride_b + c; targets [B, S_max] int32;
+ * reduction 0 = 'sum' (loss = sum_b nll_b, grad scaled by grad_scale), 1 = 'mean' (nll_b / max(S_b,1), mean over B).
+ * grad (optional) gets torch's native gradient w.r.t. log_probs, same addressing with g_stride_*.
+ * ------------------------------------------------------------------------------------------------ */
+int dyn_ctc_greedy(const float* log_probs, int64_t B, int64_t T, int64_t C, int64_t ld, int32_t blank, int32_t* argmax_ids,
+                   int32_t* out_ids, int32_t* out_len, void* stream);
+int64_t dyn_ctc_loss_workspace_bytes(int64_t T, int64_t B, int64_t S_max);
+int dyn_ctc_loss(const float* log_probs, int64_t T, int64_t B, int64_t C, int64_t lp_stride_t, int64_t lp_stride_b,
+                 const int32_t* targets, int64_t S_max, const int32_t* input_lengths, const int32_t* target_lengths,
+                 int32_t blank, int32_t reduction, float grad_scale, float* loss, float* nll_per_sample, float* grad,
+                 int64_t g_stride_t, int64_t g_stride_b, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused adaptation step over a flat fp32 parameter buffer (`optimizer.step()`, reference lcasr/lib.py:581).
+ * `step` is the 0-based count of previous steps; step == 0 initialises the state in-kernel (fresh optimiser per
+ * eval_fn call, lib.py:494).  MADGRAD follows facebookresearch/madgrad (lr+eps, cube-root denominator, momentum
+ * as an average of the dual-averaged iterate); Adam follows torch.optim.Adam (reference nvidia_ctc/lib.py:43).
+ * dyn_clip_grad_norm = torch.nn.utils.clip_grad_norm_ (reference wav2vec2/lib.py:442); norm_and_coef: 2 floats.
+ * ------------------------------------------------------------------------------------------------ */
+int dyn_madgrad_step(float* params, const float* grads, float* grad_sum, float* grad_sum_sq, float* x0, int64_t n, float lr,
+                     float momentum, float weight_decay, float eps, int64_t step, void* stream);
+int dyn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, void* stream);
+int64_t dyn_clip_grad_norm_workspace_bytes(int64_t n);
+int dyn_clip_grad_norm(float* grads, int64_t n, float max_norm, float* norm_and_coef, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Window stitching on device (reference lcasr/lib.py:583-589,604-609,615-629): acc[pos+r, c] += exp(lp[r, c]),
+ * count[pos+r] += 1, then out = log(acc / count) over the covered prefix.
+ * ------------------------------------------------------------------------------------------------ */
+int dyn_stitch_accumulate(const float* log_probs, int64_t ld, float* acc, float* count, int64_t pos, int64_t rows, int64_t C,
+                          int64_t acc_rows, void* stream);
+int dyn_stitch_finalize(const float* acc, const float* count, float* out, int64_t rows, int64_t C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
