@@ -132,6 +132,18 @@ __global__ void freq_mask_kernel(float* x, int F, int64_t T, const int32_t* __re
     for (int64_t t = (int64_t)blockIdx.x * TPB + threadIdx.x; t < T; t += (int64_t)gridDim.x * TPB) x[(int64_t)f * T + t] = value;
 }
 
+// SpecAugment time masking: columns t0[k] <= t < t0[k]+w[k] of every row set to `value`.
+__global__ void time_mask_kernel(float* x, int F, int64_t T, const int32_t* __restrict__ t0, const int32_t* __restrict__ w,
+                                 int n_masks, float value) {
+    const int k = blockIdx.y;
+    const int64_t a = t0[k], wd = w[k];
+    const int64_t total = (int64_t)F * wd;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+        const int64_t f = i / wd, t = a + i % wd;
+        if (t >= 0 && t < T) x[f * T + t] = value;
+    }
+}
+
 // [F, T] (row-major, T contiguous) -> [T, F]: the log-mel window enters the encoder channels-last.
 __global__ void transpose_ft_kernel(const float* __restrict__ x, float* __restrict__ y, int F, int64_t T, int64_t ldx) {
     __shared__ float tile[32][33];
@@ -228,6 +240,16 @@ extern "C" int dyn_specaug_freqmask(float* x, int64_t F, int64_t T, const int32_
     hipLaunchKernelGGL(freq_mask_kernel, dim3((unsigned)gx, (unsigned)F), dim3(TPB), 0, (hipStream_t)stream, x, (int)F, T,
                        f0, width, (int)n_masks, value);
     return dyn::check_launch("dyn_specaug_freqmask");
+}
+
+extern "C" int dyn_specaug_timemask(float* x, int64_t F, int64_t T, const int32_t* t0, const int32_t* width, int64_t n_masks,
+                                    float value, void* stream) {
+    DYN_REQUIRE(x && F > 0 && T >= 0 && n_masks >= 0 && (n_masks == 0 || (t0 && width)), DYN_E_ARG,
+                "dyn_specaug_timemask: bad arguments");
+    if (T == 0 || n_masks == 0) return DYN_OK;
+    hipLaunchKernelGGL(time_mask_kernel, dim3(64, (unsigned)n_masks), dim3(TPB), 0, (hipStream_t)stream, x, (int)F, T, t0, width,
+                       (int)n_masks, value);
+    return dyn::check_launch("dyn_specaug_timemask");
 }
 
 extern "C" int dyn_transpose_ft(const float* x, float* y, int64_t F, int64_t T, int64_t ldx, void* stream) {

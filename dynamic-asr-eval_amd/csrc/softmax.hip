@@ -11,8 +11,8 @@ namespace {
 constexpr int TPB = 256;
 
 template <int ITEMS, bool LOG>
-__global__ __launch_bounds__(TPB) void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows,
-                                                           int L, int64_t ldx, int64_t ldy) {
+__global__ __launch_bounds__(TPB) void softmax_fwd_kernel(const float* x, float* y, int64_t rows, int L, int64_t ldx,
+                                                           int64_t ldy) {  // y may alias x (in-place attention softmax)
     __shared__ float red[8];
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         const float* xr = x + row * ldx;

@@ -1,0 +1,401 @@
+"""Drop-in mirror of the reference's dynamic-eval library for the hot path (reference lcasr/lib.py).
+
+Same names, argument meaning and error behaviour as the reference for: `prepare_chunks` (lib.py:128-145),
+`get_specaugment_config_from_args` (:102-112), `get_frame_shuffle_config_from_args` (:114-120),
+`get_lr_args_from_args` (:122-125), `get_cutout_params_from_args` (:419-428), the freeze helpers (:163-204),
+`dynamic_eval_ctc_loss` / `dynamic_eval` (:450-643) and `apply_args` (:1756-1787).
+
+What changes is WHERE the work runs (MI355X-first):
+  * the recording's log-mel is uploaded once and windows are views of it in HBM (the reference does one H2D per
+    window, lib.py:549);
+  * posteriors never leave the device: greedy decode, CTC loss + gradient, stitching (exp / overlap-add / log) are
+    HIP kernels; only token ids (a few hundred int32) cross PCIe per window (reference: 2 D2H of [T/8, V+1] per
+    step + one per window in the final pass, lib.py:559,565,604);
+  * weight snapshot / restore is one device-to-device copy of the flat parameter buffer (reference: through host
+    memory, lib.py:482-483,636-637);
+  * forward/backward of the acoustic model and the MADGRAD/Adam step are our kernels (model.py, optim.py).
+There is no CPU fallback anywhere on this path."""
+import random
+import time
+
+import torch
+
+from . import ops
+from .augment import SpecAugment
+from .decoding import GreedyCTCDecoder
+from .optim import MADGRAD, Adam  # noqa: F401  (re-exported: `optim=lib.MADGRAD`)
+
+try:  # tqdm is optional plumbing
+    from tqdm import tqdm
+except Exception:  # pragma: no cover
+    def tqdm(x, **_):
+        return x
+
+
+# ------------------------------------------------------------------------------------------------ arg -> config helpers
+def get_specaugment_config_from_args(args):
+    a = {k.replace('spec_augment_', ''): v for k, v in args.__dict__.items() if k.startswith('spec_augment')}
+    return {
+        'n_time_masks': a.get('n_time_masks', 0),
+        'n_freq_masks': a.get('n_freq_masks', 0),
+        'freq_mask_param': a.get('freq_mask_param', 42),
+        'time_mask_param': a.get('time_mask_param', -1),
+        'min_p': a.get('min_p', 0.05),
+        'zero_masking': a.get('zero_masking', False),
+    }
+
+
+def get_frame_shuffle_config_from_args(args):
+    a = {k.replace('frame_shuffle_', ''): v for k, v in args.__dict__.items() if k.startswith('frame_shuffle')}
+    return {'time_dimension': a.get('time_dimension', False), 'freq_dimension': a.get('freq_dimension', False)}
+
+
+def get_lr_args_from_args(args):
+    lr_args = {k.replace('optim_', ''): v for k, v in args.__dict__.items() if k.startswith('optim_')}
+    lr_args['lr'] = lr_args.get('lr', 9e-5)
+    return lr_args
+
+
+def get_cutout_params_from_args(args, seq_len):
+    a = {k.replace('cutout_', ''): v for k, v in args.__dict__.items() if k.startswith('cutout')}
+    return {
+        'seq_len': seq_len,
+        'cutout_val': a.get('value', 'mean'),
+        'num_rectangles': a.get('num_rectangles', 0),
+        'max_width': a.get('max_width', 100),
+        'max_height': a.get('max_height', 10),
+    }
+
+
+def prepare_chunks(spec, seq_len, overlap):
+    """Window index set, exactly as reference lcasr/lib.py:128-145: stride seq_len - overlap; windows are kept until
+    ONE window shorter than its predecessor has been added; a single window when the recording fits."""
+    spec_n = spec.shape[-1]
+    last_ulen, kill_next = None, False
+    if spec_n <= seq_len:
+        return {0: spec}, [0]
+    training_data = {}
+    for i in range(0, spec_n, seq_len - overlap):
+        audio_chunk = spec[:, :, i:i + seq_len]  # [B, C, T] view
+        u_len = audio_chunk.shape[-1]
+        if kill_next:
+            break
+        elif last_ulen is not None and u_len < last_ulen:
+            kill_next = True
+        last_ulen = u_len
+        training_data[i] = audio_chunk
+    return training_data, list(training_data.keys())
+
+
+# ------------------------------------------------------------------------------------------------ freeze helpers
+def _set_frozen(model, prefixes=None, only=None):
+    if hasattr(model, "frozen"):  # our SCConformerXL
+        if only is not None:
+            model.frozen = {n for n, _ in model.spec if not any(n.startswith(o) for o in only)}
+        else:
+            model.frozen = set(model.frozen) | set(prefixes)
+    else:  # foreign torch module: same attribute the reference flips
+        for n, p in model.named_parameters():
+            if only is not None:
+                p.requires_grad = any(n.startswith(o) for o in only)
+            elif any(n.startswith(f) for f in prefixes):
+                p.requires_grad = False
+    return model
+
+
+def freeze_subsampling(model):
+    if getattr(model, 'subsampling', None) is None:
+        print('No subsampling module found to freeze')
+        return model
+    print('Freezing subsampling module')
+    return _set_frozen(model, prefixes=['subsampling.'])
+
+
+def freeze_all_but_last_block_and_head(model):
+    n = len(model.layers)
+    print(f'Training only last block: layers.{n - 1} and CTC head')
+    return _set_frozen(model, only=[f'layers.{n - 1}.', 'decoder.'])
+
+
+def train_subsampling_only(model):
+    if getattr(model, 'subsampling', None) is None:
+        print('No subsampling module found to train')
+        return model
+    print('Training only subsampling module')
+    return _set_frozen(model, only=['subsampling.'])
+
+
+# ------------------------------------------------------------------------------------------------ the hot path
+def _is_native(model):
+    return hasattr(model, "flat_params") and hasattr(model, "backward")
+
+
+def _window_fill_value(window, zero_masking):
+    if zero_masking:
+        return 0.0
+    F, T = window.shape
+    tmp = torch.zeros(T, device=window.device, dtype=torch.float32)
+    ops.colsum(window, tmp, beta=0.0)
+    tot = torch.zeros(1, device=window.device, dtype=torch.float32)
+    ops.colsum(tmp.view(T, 1), tot, beta=0.0)
+    return float(tot.item()) / float(F * T)
+
+
+def _unsupported(name):
+    raise NotImplementedError(f"{name} is an optional augmentation of the reference that the HIP path does not implement "
+                              "yet; refusing to silently run without it")
+
+
+def dynamic_eval_ctc_loss(
+        args,
+        model,
+        spec: torch.Tensor,
+        seq_len: int,
+        overlap: int,
+        tokenizer,
+        use_tqdm=True,
+        optim=MADGRAD,
+        optimizer_state: dict = None,
+        beam_search_fn=None,
+        return_params: bool = False,
+        return_device: bool = False,
+):
+    """Reference lcasr/lib.py:450-640.  Returns np.float32 [T_ds, V+1] log-probs (and the adapted parameters as CPU
+    clones when `return_params`).  `return_device=True` (extension) returns the stitched log-probs as a CUDA tensor so
+    the harness can decode them without a PCIe round trip."""
+    if beam_search_fn is not None and args.__dict__.get('lm_tta_beams', 3) != 0:
+        _unsupported("LM beam-search pseudo-labels (beam_search_fn)")
+    device = model.device
+    if torch.device(device).type != "cuda":
+        raise ops.DynError("dynamic_eval: model.device must be a GPU (no CPU fallback)")
+    spec_n = spec.shape[-1]
+    downsampling_factor = args.config['model']['subsampling_factor']
+    seq_len = seq_len if seq_len != -1 else args.config['audio_chunking']['size']
+
+    spec_augment_config = get_specaugment_config_from_args(args)
+    random_noise = args.__dict__.get('random_noise', 0.0)
+    lr_args = get_lr_args_from_args(args)
+    frame_shuffle_args = get_frame_shuffle_config_from_args(args)
+    entropy_args = {k.replace('entropy_augmentation_', ''): v for k, v in args.__dict__.items()
+                    if k.startswith('entropy_augmentation_')}
+    cutout_args = get_cutout_params_from_args(args, seq_len)
+    verbose = bool(args.__dict__.get('verbose', False)) and not args.__dict__.get('quiet', False)
+    if verbose:
+        print(spec_augment_config, lr_args, frame_shuffle_args, cutout_args)
+    if random_noise:
+        _unsupported("random_noise")
+    if frame_shuffle_args['time_dimension'] or frame_shuffle_args['freq_dimension']:
+        _unsupported("frame_shuffle")
+    if cutout_args['num_rectangles']:
+        _unsupported("cutout")
+    if entropy_args.get('enabled', False):
+        _unsupported("entropy_augmentation")
+    num_negatives = 1
+    native = _is_native(model)
+
+    # snapshot of the weights, kept in HBM (reference: CPU clones, lib.py:482-483)
+    if native:
+        original_flat = model.flat_params.clone()
+        frozen_before = set(model.frozen)
+    else:
+        original_model_params = [p.clone().detach() for p in model.parameters()]
+
+    if args.__dict__.get('freeze_subsampling', False):
+        model = freeze_subsampling(model)
+    if args.__dict__.get('freeze_all_but_last_block_and_head', False):
+        model = freeze_all_but_last_block_and_head(model)
+    if args.__dict__.get('train_subsampling_only', False):
+        model = train_subsampling_only(model)
+
+    num_classes = model.decoder.num_classes
+    blank = num_classes - 1
+    optimizer = optim(model.parameters(), **lr_args)
+    if optimizer_state is not None:
+        optimizer.load_state_dict(optimizer_state)
+
+    decoder = GreedyCTCDecoder(tokenizer=tokenizer, blank_id=blank, device=device)
+    augmentation = SpecAugment(**spec_augment_config)
+    fixed_masks = args.__dict__.get('spec_augment_fixed_masks', None)  # test hook: {window_key: masks}
+
+    if seq_len > spec_n:
+        seq_len, overlap = spec_n, 0
+    else:
+        overlap = overlap if overlap != -1 else args.config['audio_chunking']['overlap']
+
+    assert args.config['training'].get("max_seq_len", 0) == 0, 'caching is not used anymore'
+    assert overlap / downsampling_factor == overlap // downsampling_factor, 'Overlap must be a multiple of the downsampling factor'
+    if verbose:
+        print(f'Using seq_len: {seq_len} and overlap: {overlap}')
+    assert tokenizer.vocab_size() + 1 == num_classes, 'tokenizer vocabulary does not match the CTC head'
+
+    epochs = args.__dict__.get('epochs', 1)
+    shuffle = args.__dict__.get('shuffle', False)
+    online = args.__dict__.get('online', False)
+    epochs = 1 if online else epochs
+    shuffle = False if online else shuffle
+    print_runtimes = args.__dict__.get('print_runtimes', False)
+    skip_zero = args.__dict__.get('skip_zero_grad_samples', True)
+    final_batch = int(args.__dict__.get('final_pass_batch', 4))
+    if print_runtimes:
+        print('Spectrogram length:', spec_n)
+
+    # the whole recording lives in HBM; windows are views (one upload instead of one per window)
+    spec_dev = spec.to(device=device, dtype=torch.float32)
+    if spec_dev.dim() != 3 or spec_dev.shape[0] != 1:
+        raise ops.DynError(f"spec must be [1, F, T], got {tuple(spec.shape)}")
+    Fq = spec_dev.shape[1]
+
+    # on-device stitch accumulators (reference: two host buffers of spec_n//4 + seq_len rows, lib.py:510)
+    acc_rows = spec_n // 4 + seq_len
+    acc = torch.zeros(acc_rows, num_classes, device=device, dtype=torch.float32)
+    cnt = torch.zeros(acc_rows, device=device, dtype=torch.float32)
+    stitch = {"pos": 0, "end": 0}
+
+    def stitch_window(key, log_probs_2d, u_len):
+        ds_len = log_probs_2d.shape[0]
+        ratio = u_len / ds_len
+        overlap_ds = int(overlap / ratio)
+        stitch["pos"] -= overlap_ds if key != 0 else 0
+        ops.stitch_accumulate(log_probs_2d, acc, cnt, stitch["pos"])
+        stitch["pos"] += ds_len
+        stitch["end"] = max(stitch["end"], stitch["pos"])
+
+    model.eval()  # don't update batchrenorm (reference lib.py:525)
+    training_data, training_keys = prepare_chunks(spec_dev, seq_len, overlap)
+    for epoch in range(args.__dict__.get('epochs', 1)):
+        if verbose:
+            print(f'Epoch {epoch + 1} / {epochs}')
+        training_keys = list(training_data.keys())
+        training_keys = random.sample(training_keys, len(training_keys)) if shuffle else training_keys
+        epochs_stime = time.time()
+        pbar = tqdm(training_keys) if use_tqdm else training_keys
+        for i in pbar:
+            view = training_data[i][0]  # [F, u_len] view into the recording
+            u_len = view.shape[-1]
+            audio_chunk = torch.empty(num_negatives + 1, Fq, u_len, device=device, dtype=torch.float32)
+            for b in range(num_negatives + 1):
+                audio_chunk[b].copy_(view)
+            for b in range(num_negatives):  # augment copy 0, copy -1 stays clean (reference lib.py:541)
+                masks = fixed_masks[i] if fixed_masks is not None else augmentation.draw(Fq, u_len)
+                if masks[0][0] or masks[1][0]:
+                    fill = _window_fill_value(audio_chunk[b], augmentation.zero_masking)
+                    augmentation.apply(audio_chunk[b], masks, fill)
+
+            with torch.enable_grad():
+                out = model(audio_signal=audio_chunk)
+            post = out['final_posteriors']  # [B, N, C] on device
+
+            pseudo_targets = decoder(post[-1].detach())  # greedy ids on device -> text (reference lib.py:559)
+            if verbose and not args.__dict__.get('not_verbose', False) and args.__dict__.get('print_predictions', False):
+                print(f'Pseudo targets: {pseudo_targets}')
+                print(f'Noisy predictions: {decoder(post[0].detach())}\n--\n')
+            target_ids = tokenizer.encode(pseudo_targets)  # text hop kept (reference lib.py:569)
+            S = len(target_ids)
+            targets = torch.tensor([target_ids if S else [0]] * num_negatives, dtype=torch.int32, device=device)
+            augmented_outs = post[:num_negatives]
+            N, B = augmented_outs.shape[1], augmented_outs.shape[0]
+            total_tokens_in_loss = N * B
+            ilen = torch.full((B,), N, dtype=torch.int32, device=device)
+            tlen = torch.full((B,), S, dtype=torch.int32, device=device)
+
+            if native:
+                # CTCLoss(reduction='sum') / (N*B) and its gradient w.r.t. the log-probs (reference lib.py:575,579)
+                _, _, g_aug = ops.ctc_loss(augmented_outs.contiguous(), targets, ilen, tlen, blank, reduction="sum",
+                                           grad_scale=1.0 / total_tokens_in_loss)
+                optimizer.zero_grad()
+                if skip_zero:
+                    model.backward(g_aug, n_active=num_negatives)  # the clean copy's gradient is identically zero
+                else:
+                    g_full = torch.zeros_like(post)
+                    g_full[:num_negatives].copy_(g_aug)
+                    model.backward(g_full)
+            else:
+                _, _, g_aug = ops.ctc_loss(augmented_outs.detach().contiguous(), targets, ilen, tlen, blank, reduction="sum",
+                                           grad_scale=1.0 / total_tokens_in_loss)
+                optimizer.zero_grad()
+                augmented_outs.backward(g_aug)
+            optimizer.step()
+
+            if online:
+                stitch_window(i, post[-1].detach(), u_len)
+        epochs_etime = time.time()
+        if print_runtimes:
+            torch.cuda.synchronize(device)
+            print(f'Epoch runtime: {time.time() - epochs_stime}')
+            del epochs_etime
+
+    if not online:
+        model.eval()
+        training_data, training_keys = prepare_chunks(spec_dev, seq_len, overlap)
+        final_pass_stime = time.time()
+        keys = sorted(training_keys)
+        idx = 0
+        with torch.no_grad():
+            while idx < len(keys):
+                # windows are independent here: batch equal-length ones to fill the GPU (reference: B = 1, lib.py:599-609)
+                group = [keys[idx]]
+                u_len = training_data[keys[idx]].shape[-1]
+                while len(group) < final_batch and idx + len(group) < len(keys) and \
+                        training_data[keys[idx + len(group)]].shape[-1] == u_len:
+                    group.append(keys[idx + len(group)])
+                batch = torch.empty(len(group), Fq, u_len, device=device, dtype=torch.float32)
+                for b, k in enumerate(group):
+                    batch[b].copy_(training_data[k][0])
+                post = model(audio_signal=batch)['final_posteriors']
+                for b, k in enumerate(group):
+                    stitch_window(k, post[b], u_len)
+                idx += len(group)
+        if print_runtimes:
+            torch.cuda.synchronize(device)
+            print(f'Final pass runtime: {time.time() - final_pass_stime}')
+        model.train()
+
+    logits_dev = ops.stitch_finalize(acc, cnt, stitch["end"])  # log(sum / count) over the covered rows
+
+    if return_params:
+        updated_model_params = [p.clone().detach().cpu() for p in model.parameters()]
+
+    # reset model parameters (reference lib.py:636-637)
+    if native:
+        model.flat_params.copy_(original_flat)
+        model.frozen = frozen_before
+    else:
+        for p, p_orig in zip(model.parameters(), original_model_params):
+            p.data = p_orig.data.to(p.device)
+
+    logits = logits_dev if return_device else logits_dev.cpu().numpy()
+    return logits if not return_params else (logits, updated_model_params)
+
+
+dynamic_eval = dynamic_eval_ctc_loss
+
+
+# ------------------------------------------------------------------------------------------------ shared CLI surface
+def apply_args(parser, argv=None):
+    """Reference lcasr/lib.py:1756-1787 (same flags, same free-form `-kwargs k=v` evaluated into args.__dict__)."""
+    parser.add_argument('-c', '--checkpoint', type=str, default='', help='path to checkpoint')
+    parser.add_argument('-split', '--split', type=str, default='test', help='test or dev split')
+    parser.add_argument('-seq', '--seq_len', type=int, default=16384, help='-1 to use setting from config in checkpoint file')
+    parser.add_argument('-o', '--overlap', type=int, default=14336, help='-1 to use setting from config in checkpoint file')
+    parser.add_argument('-nv', '--not_verbose', action='store_true', help='verbose')
+    parser.add_argument('-log', '--log', type=str, default='')
+    parser.add_argument('-ds', '--dont_shuffle', action='store_true', help='dont shuffle')
+    parser.add_argument('-epochs', '--epochs', type=int, default=1, help='epochs')
+    parser.add_argument('-dfa', '--disable_flash_attention', action='store_true', help='disable flash attention')
+    parser.add_argument('-beamsearch', '--beamsearch', action='store_true', help='use beam search')
+    parser.add_argument('-kwargs', '--kwargs', nargs='+', help='kwargs')
+    parser.add_argument('-awmc', '--awmc', action='store_true', help='Use AWMC instead of dynamic eval')
+    parser.add_argument('--consistency', '--consistency', action='store_true', help='Use consistency training')
+    parser.add_argument('--freeze_subsampling', action='store_true')
+    parser.add_argument('--freeze_all_but_last_block_and_head', action='store_true')
+    parser.add_argument('--train_subsampling_only', action='store_true')
+    args = parser.parse_args(argv)
+    if args.kwargs is None:
+        args.kwargs = []
+    for kwarg in args.kwargs:
+        key, value = kwarg.split('=')
+        args.__dict__[key] = eval(value)  # same free-form override as the reference (lib.py:1780)
+        print(f'Overriding {key} to {value}')
+    args.shuffle = not args.dont_shuffle
+    args.verbose = not args.not_verbose
+    return args

@@ -1,0 +1,445 @@
+"""SCConformerXL on MI355X: the acoustic model the reference drives through
+`model(audio_signal=...)['final_posteriors']` (reference lcasr/lib.py:550,559,603), with an explicit
+forward / backward built ONLY from the HIP kernels of libdyneval_hip.so (no torch arithmetic, no autograd).
+
+Duck-type surface kept from the reference: callable with kw `audio_signal` ([B, 80, T] log-mel),
+returns {'final_posteriors': [B, T/8, V+1] log-probs, blank = last class}; `.device`, `.decoder.num_classes`,
+`.parameters()`, `.eval()/.train()`, `.subsampling`, `.layers`, `.decoder`, `.print_total_params()`,
+`.load_state_dict(strict=False)`.  Activations are saved for the backward exactly when torch grad mode is on,
+so `with torch.no_grad(): model(...)` (reference lib.py:603) behaves as in the reference.
+
+HBM layout (MI355X-first): all parameters live in ONE flat fp32 buffer (256-B aligned slots), all gradients in a
+second, so the adaptation step is a single fused launch over ~90 M elements and snapshot/restore of the weights is
+one device-to-device copy (the reference round-trips them through host memory, lib.py:482-483,636-637).
+Activations are channels-last ([B, T, C]) so pointwise convs and linears are plain row-major GEMMs and every
+elementwise kernel is coalesced along C.  Architecture: see oracle/conformer_ref.py (same definition, shared names).
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from .optim import ParamList
+
+DEFAULT_CONFIG = dict(
+    feat_in=80, n_layers=6, d_model=768, n_heads=6, head_dim=128, ff_mult=4, subsampling_factor=8,
+    subsampling_conv_channels=256, conv_kernel_size=9, conv_norm="rms_norm", rotary_base_freq=1500000.0,
+    self_conditioning=True, norm_eps=1e-5,
+)
+
+
+def make_config(**over):
+    cfg = dict(DEFAULT_CONFIG)
+    for k, v in over.items():
+        if k in DEFAULT_CONFIG:
+            cfg[k] = v
+    return cfg
+
+
+def param_spec(cfg, num_classes):
+    """[(name, shape)] in the oracle's named_parameters() order."""
+    d, C, K = cfg["d_model"], cfg["subsampling_conv_channels"], cfg["conv_kernel_size"]
+    HD, ff = cfg["n_heads"] * cfg["head_dim"], cfg["d_model"] * cfg["ff_mult"]
+    fo = cfg["feat_in"]
+    for _ in range(3):
+        fo = ops.out_len(fo)
+    spec = [("subsampling.conv1.weight", (C, 3, 3)), ("subsampling.conv1.bias", (C,))]
+    for i in (2, 3):
+        spec += [(f"subsampling.dw{i}.weight", (C, 3, 3)), (f"subsampling.dw{i}.bias", (C,)),
+                 (f"subsampling.pw{i}.weight", (C, C)), (f"subsampling.pw{i}.bias", (C,))]
+    spec += [("subsampling.out.weight", (d, fo * C)), ("subsampling.out.bias", (d,))]
+    for l in range(cfg["n_layers"]):
+        p = f"layers.{l}."
+        for ffn in ("ff1",):
+            spec += [(p + ffn + ".norm.weight", (d,)), (p + ffn + ".norm.bias", (d,)),
+                     (p + ffn + ".w1.weight", (ff, d)), (p + ffn + ".w2.weight", (d, ff))]
+        spec += [(p + "attn.norm.weight", (d,)), (p + "attn.norm.bias", (d,)), (p + "attn.qkv.weight", (3 * HD, d)),
+                 (p + "attn.qkv.bias", (3 * HD,)), (p + "attn.out.weight", (d, HD)), (p + "attn.out.bias", (d,))]
+        spec += [(p + "conv.norm.weight", (d,)), (p + "conv.norm.bias", (d,)), (p + "conv.pw1.weight", (2 * d, d)),
+                 (p + "conv.pw1.bias", (2 * d,)), (p + "conv.dw.weight", (d, K)), (p + "conv.dw.bias", (d,)),
+                 (p + "conv.cnorm.weight", (d,))]
+        if cfg["conv_norm"] != "rms_norm":
+            spec += [(p + "conv.cnorm.bias", (d,))]
+        spec += [(p + "conv.pw2.weight", (d, d)), (p + "conv.pw2.bias", (d,))]
+        spec += [(p + "ff2.norm.weight", (d,)), (p + "ff2.norm.bias", (d,)), (p + "ff2.w1.weight", (ff, d)),
+                 (p + "ff2.w2.weight", (d, ff))]
+        spec += [(p + "norm_out.weight", (d,)), (p + "norm_out.bias", (d,))]
+    spec += [("decoder.norm.weight", (d,)), ("decoder.norm.bias", (d,)), ("decoder.ff.weight", (num_classes, d)),
+             ("decoder.ff.bias", (num_classes,))]
+    if cfg["self_conditioning"]:
+        spec += [("decoder.reproj.weight", (d, num_classes)), ("decoder.reproj.bias", (d,))]
+    return spec
+
+
+class _Group:
+    """A named slice of the parameter list (`model.subsampling`, `model.layers[i]`, `model.decoder`): what the
+    reference's freeze helpers iterate (reference lcasr/lib.py:163-204)."""
+
+    def __init__(self, model, prefix, **attrs):
+        self._model, self._prefix = model, prefix
+        self.__dict__.update(attrs)
+
+    def parameters(self):
+        return [p for n, p in self._model.named_parameters() if n.startswith(self._prefix)]
+
+
+class SCConformerXL:
+    def __init__(self, config=None, vocab_size=128, device="cuda:0"):
+        self.config = make_config(**(config or {}))
+        cfg = self.config
+        if cfg["conv_norm"] not in ("rms_norm", "layer_norm", "batch_renorm"):
+            raise ValueError(f"unknown conv_norm {cfg['conv_norm']}")
+        if cfg["d_model"] % 256:
+            raise ValueError("d_model must be a multiple of 256 (wave-per-row norm kernels)")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ops.DynError("SCConformerXL runs only on the HIP path (device must be cuda)")
+        self.num_classes = vocab_size + 1
+        self.spec = param_spec(cfg, self.num_classes)
+        off, self._slots = 0, {}
+        for name, shape in self.spec:
+            n = math.prod(shape)
+            self._slots[name] = (off, n, shape)
+            off += (n + 63) // 64 * 64
+        self.n_flat = off
+        self.flat_params = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.flat_grads = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.P, self.G = {}, {}
+        for name, (o, n, shape) in self._slots.items():
+            self.P[name] = self.flat_params[o:o + n].view(shape)
+            self.G[name] = self.flat_grads[o:o + n].view(shape)
+        self.buffers = {}
+        if cfg["conv_norm"] == "batch_renorm":
+            for l in range(cfg["n_layers"]):
+                self.buffers[f"layers.{l}.conv.cnorm.running_mean"] = torch.zeros(cfg["d_model"], device=self.device)
+                self.buffers[f"layers.{l}.conv.cnorm.running_var"] = torch.ones(cfg["d_model"], device=self.device)
+        self.frozen = set()  # parameter-name prefixes excluded from adaptation
+        self.subsampling = _Group(self, "subsampling.")
+        self.layers = [_Group(self, f"layers.{l}.") for l in range(cfg["n_layers"])]
+        self.decoder = _Group(self, "decoder.", num_classes=self.num_classes)
+        self._rot = {}
+        self._ctx = None
+        self.training = False
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def named_parameters(self):
+        return [(n, self.P[n]) for n, _ in self.spec]
+
+    def parameters(self):
+        pl = ParamList(self.P[n] for n, _ in self.spec)
+        pl.flat_params, pl.flat_grads = self.flat_params, self.flat_grads
+        return pl
+
+    def grads(self):
+        return [self.G[n] for n, _ in self.spec]
+
+    def state_dict(self):
+        sd = {n: p.detach().clone() for n, p in self.named_parameters()}
+        sd.update({n: b.detach().clone() for n, b in self.buffers.items()})
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [n for n, _ in self.spec if n not in sd]
+        unexpected = [n for n in sd if n not in self.P and n not in self.buffers]
+        if strict and (missing or unexpected):
+            raise KeyError(f"missing {missing[:5]}… unexpected {unexpected[:5]}…")
+        for n, _ in self.spec:
+            if n in sd:
+                self.P[n].copy_(sd[n].to(self.device, torch.float32).reshape(self.P[n].shape))
+        for n in self.buffers:
+            if n in sd:
+                self.buffers[n].copy_(sd[n].to(self.device, torch.float32))
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device and torch.device(device).type != "cuda":
+            raise ops.DynError("SCConformerXL cannot leave the GPU: there is no CPU path")
+        return self
+
+    def print_total_params(self):
+        print(f"Total params: {sum(math.prod(s) for _, s in self.spec) / 1e6:.2f}M")
+
+    def zero_grad(self):
+        self.flat_grads.zero_()
+
+    def trainable(self, name):
+        return not any(name.startswith(f) for f in self.frozen)
+
+    # ------------------------------------------------------------------ helpers
+    def _rotary(self, T):
+        if T not in self._rot:
+            D = self.config["head_dim"]
+            inv = 1.0 / (float(self.config["rotary_base_freq"]) ** (torch.arange(0, D, 2, dtype=torch.float64) / D))
+            ang = torch.arange(T, dtype=torch.float64)[:, None] * inv[None]
+            self._rot = {T: (ang.cos().float().to(self.device).contiguous(), ang.sin().float().to(self.device).contiguous())}
+        return self._rot[T]
+
+    def _lin_bwd(self, dy, x, wname, bname=None, need_dx=True, alpha=1.0):
+        """Accumulates dW (and db) for y = x @ W^T + b and returns alpha * dy @ W (or None)."""
+        if self.trainable(wname):
+            ops.linear_wgrad(dy, x, self.G[wname], alpha=alpha, beta=1.0)
+            if bname is not None:
+                ops.colsum(dy, self.G[bname], beta=1.0)
+        return ops.linear_dgrad(dy, self.P[wname], alpha=alpha) if need_dx else None
+
+    # ------------------------------------------------------------------ forward
+    def __call__(self, audio_signal=None, **kw):
+        return self.forward(audio_signal)
+
+    def forward(self, audio_signal):
+        x = audio_signal
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
+            raise ops.DynError("audio_signal must be a float32 CUDA tensor [B, feat_in, T]")
+        cfg, P = self.config, self.P
+        save = torch.is_grad_enabled()
+        ctx = {} if save else None
+        B, Fq, T = x.shape
+        assert Fq == cfg["feat_in"], (Fq, cfg["feat_in"])
+        C = cfg["subsampling_conv_channels"]
+        xt = torch.empty(B, T, Fq, device=x.device, dtype=torch.float32)
+        for b in range(B):
+            ops.transpose_ft(x[b], out=xt[b])
+        # --- dw_striding x8 subsampling
+        z1 = ops.conv2d_first(xt, P["subsampling.conv1.weight"], P["subsampling.conv1.bias"])
+        u2 = ops.dwconv2d_s2(z1, P["subsampling.dw2.weight"], P["subsampling.dw2.bias"])
+        z2 = ops.linear(u2, P["subsampling.pw2.weight"], P["subsampling.pw2.bias"])
+        u3 = ops.dwconv2d_s2(z2, P["subsampling.dw3.weight"], P["subsampling.dw3.bias"])
+        z3 = ops.linear(u3, P["subsampling.pw3.weight"], P["subsampling.pw3.bias"])
+        a3 = ops.silu(z3)
+        T3, F3 = a3.shape[1], a3.shape[2]
+        h = ops.linear(a3.view(B, T3, F3 * C), P["subsampling.out.weight"], P["subsampling.out.bias"])
+        if save:
+            ctx["sub"] = (xt, z1, u2, z2, u3, z3, a3)
+            ctx["layers"] = []
+            ctx["sc"] = []
+        nl = cfg["n_layers"]
+        for l in range(nl):
+            lc = {} if save else None
+            p = f"layers.{l}."
+            h = self._ff_fwd(h, p + "ff1", lc, "ff1")
+            h = self._attn_fwd(h, p + "attn", lc)
+            h = self._conv_fwd(h, p + "conv", lc)
+            h = self._ff_fwd(h, p + "ff2", lc, "ff2")
+            hn, mean, rstd = ops.layernorm(h, P[p + "norm_out.weight"], P[p + "norm_out.bias"], cfg["norm_eps"])
+            if save:
+                lc["norm_out"] = (h, mean, rstd)
+                ctx["layers"].append(lc)
+            h = hn
+            if cfg["self_conditioning"] and l != nl - 1:
+                n, mean, rstd = ops.layernorm(h, P["decoder.norm.weight"], P["decoder.norm.bias"], cfg["norm_eps"])
+                z = ops.linear(n, P["decoder.ff.weight"], P["decoder.ff.bias"])
+                ops.softmax(z, out=z)
+                h2 = h.clone() if save else h
+                ops.linear(z, P["decoder.reproj.weight"], P["decoder.reproj.bias"], out=h2, beta=1.0)
+                if save:
+                    ctx["sc"].append((h, mean, rstd, n, z))
+                h = h2
+        n, mean, rstd = ops.layernorm(h, P["decoder.norm.weight"], P["decoder.norm.bias"], cfg["norm_eps"])
+        z = ops.linear(n, P["decoder.ff.weight"], P["decoder.ff.bias"])
+        logp = ops.log_softmax(z, out=z)
+        if save:
+            ctx["head"] = (h, mean, rstd, n, logp)
+            ctx["dims"] = (B, T, T3, F3)
+        self._ctx = ctx
+        return {"final_posteriors": logp}
+
+    def _ff_fwd(self, h, p, lc, key):
+        P, eps = self.P, self.config["norm_eps"]
+        n, mean, rstd = ops.layernorm(h, P[p + ".norm.weight"], P[p + ".norm.bias"], eps)
+        u = ops.linear(n, P[p + ".w1.weight"])
+        a = ops.silu(u)
+        out = h.clone() if lc is not None else h
+        ops.linear(a, P[p + ".w2.weight"], out=out, alpha=0.5, beta=1.0)
+        if lc is not None:
+            lc[key] = (h, mean, rstd, n, u, a)
+        return out
+
+    def _attn_fwd(self, h, p, lc):
+        cfg, P = self.config, self.P
+        H, D = cfg["n_heads"], cfg["head_dim"]
+        HD = H * D
+        B, T, _ = h.shape
+        n, mean, rstd = ops.layernorm(h, P[p + ".norm.weight"], P[p + ".norm.bias"], cfg["norm_eps"])
+        qkv = ops.linear(n, P[p + ".qkv.weight"], P[p + ".qkv.bias"])
+        cos, sin = self._rotary(T)
+        ops.rotary(qkv, cos, sin, B, T, 2 * H, D, 3 * HD)
+        S = torch.empty(B, H, T, T, device=h.device, dtype=torch.float32)
+        ops.gemm(qkv, qkv, S, trans_b=True, M=T, N=T, K=D, lda=3 * HD, ldb=3 * HD, ldc=T, nb1=B, nb2=H,
+                 sa=(T * 3 * HD, D), sb=(T * 3 * HD, D), sc=(H * T * T, T * T), b_off=HD, alpha=1.0 / math.sqrt(D))
+        ops.softmax(S, out=S)
+        O = torch.empty(B, T, HD, device=h.device, dtype=torch.float32)
+        ops.gemm(S, qkv, O, M=T, N=D, K=T, lda=T, ldb=3 * HD, ldc=HD, nb1=B, nb2=H, sa=(H * T * T, T * T),
+                 sb=(T * 3 * HD, D), sc=(T * HD, D), b_off=2 * HD)
+        out = h.clone() if lc is not None else h
+        ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], out=out, beta=1.0)
+        if lc is not None:
+            lc["attn"] = (h, mean, rstd, n, qkv, S, O)
+        return out
+
+    def _cnorm_fwd(self, c, p):
+        cfg, P = self.config, self.P
+        kind = cfg["conv_norm"]
+        if kind == "rms_norm":
+            y, rstd = ops.rmsnorm(c, P[p + ".cnorm.weight"], cfg["norm_eps"])
+            return y, (None, rstd)
+        if kind == "layer_norm":
+            y, mean, rstd = ops.layernorm(c, P[p + ".cnorm.weight"], P[p + ".cnorm.bias"], cfg["norm_eps"])
+            return y, (mean, rstd)
+        raise ops.DynError("conv_norm='batch_renorm' is not available on the HIP path yet")
+
+    def _conv_fwd(self, h, p, lc):
+        cfg, P = self.config, self.P
+        n, mean, rstd = ops.layernorm(h, P[p + ".norm.weight"], P[p + ".norm.bias"], cfg["norm_eps"])
+        u = ops.linear(n, P[p + ".pw1.weight"], P[p + ".pw1.bias"])
+        g = ops.glu(u)
+        c = ops.dwconv1d(g, P[p + ".dw.weight"], P[p + ".dw.bias"])
+        nn_, stats = self._cnorm_fwd(c, p)
+        s = ops.silu(nn_)
+        out = h.clone() if lc is not None else h
+        ops.linear(s, P[p + ".pw2.weight"], P[p + ".pw2.bias"], out=out, beta=1.0)
+        if lc is not None:
+            lc["conv"] = (h, mean, rstd, n, u, g, c, stats, nn_, s)
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, grad_posteriors, n_active=None):
+        """Gradient of a scalar loss w.r.t. every parameter, given dL/d(final_posteriors) [B, T', V+1].
+        Accumulates into `flat_grads` (call zero_grad() first, as `optimizer.zero_grad()` at reference lib.py:578).
+        `n_active` = nb: only the first nb samples of the batch carry a non-zero gradient (the dynamic-eval loss uses
+        the augmented copies only, reference lib.py:570-575), so the backward runs on those samples; the skipped
+        samples would contribute exact zeros to every gradient."""
+        ctx = self._ctx
+        if ctx is None:
+            raise ops.DynError("backward() without a grad-mode forward")
+        cfg, P, G = self.config, self.P, self.G
+        B, T, T3, F3 = ctx["dims"]
+        nb = B if n_active is None else int(n_active)
+        if grad_posteriors.shape[0] != nb:
+            raise ops.DynError(f"backward: gradient batch {grad_posteriors.shape[0]} != active samples {nb}")
+        if nb != B:
+            rows = nb * T3
+
+            def cut(t):
+                if isinstance(t, tuple):
+                    return tuple(cut(x) for x in t)
+                if t is None:
+                    return None
+                return t[:rows] if t.dim() == 1 else t[:nb]
+
+            ctx["head"] = cut(ctx["head"])
+            ctx["sc"] = [cut(s) for s in ctx["sc"]]
+            ctx["layers"] = [{k: cut(v) for k, v in lc.items()} for lc in ctx["layers"]]
+            ctx["sub"] = cut(ctx["sub"])
+            ctx["dims"] = (nb, T, T3, F3)
+        h, mean, rstd, n, logp = ctx["head"]
+        dz = ops.log_softmax_bwd(logp, grad_posteriors.contiguous())
+        dn = self._lin_bwd(dz, n, "decoder.ff.weight", "decoder.ff.bias")
+        dh = torch.empty_like(h)
+        ops.layernorm_bwd(h, P["decoder.norm.weight"], mean, rstd, dn, dh, G["decoder.norm.weight"], G["decoder.norm.bias"],
+                          dx_beta=0.0)
+        nl = cfg["n_layers"]
+        for l in reversed(range(nl)):
+            if cfg["self_conditioning"] and l != nl - 1:
+                h0, mean, rstd, n, pz = ctx["sc"][l]
+                dp = self._lin_bwd(dh, pz, "decoder.reproj.weight", "decoder.reproj.bias")
+                dzz = ops.softmax_bwd(pz, dp, out=dp)
+                dn = self._lin_bwd(dzz, n, "decoder.ff.weight", "decoder.ff.bias")
+                ops.layernorm_bwd(h0, P["decoder.norm.weight"], mean, rstd, dn, dh, G["decoder.norm.weight"],
+                                  G["decoder.norm.bias"], dx_beta=1.0)
+            lc = ctx["layers"][l]
+            p = f"layers.{l}."
+            h0, mean, rstd = lc["norm_out"]
+            dh2 = torch.empty_like(dh)
+            ops.layernorm_bwd(h0, P[p + "norm_out.weight"], mean, rstd, dh, dh2, G[p + "norm_out.weight"],
+                              G[p + "norm_out.bias"], dx_beta=0.0)
+            dh = dh2
+            self._ff_bwd(dh, p + "ff2", lc["ff2"])
+            self._conv_bwd(dh, p + "conv", lc["conv"])
+            self._attn_bwd(dh, p + "attn", lc["attn"])
+            self._ff_bwd(dh, p + "ff1", lc["ff1"])
+            ctx["layers"][l] = None  # release this block's activations
+        self._sub_bwd(dh, ctx)
+        self._ctx = None
+        for name, _ in self.spec:
+            if not self.trainable(name):
+                self.G[name].zero_()
+
+    def _ff_bwd(self, dh, p, saved):
+        h, mean, rstd, n, u, a = saved
+        P, G = self.P, self.G
+        da = self._lin_bwd(dh, a, p + ".w2.weight", None, alpha=0.5)
+        du = ops.silu_bwd(u, da, out=da)
+        dn = self._lin_bwd(du, n, p + ".w1.weight", None)
+        ops.layernorm_bwd(h, P[p + ".norm.weight"], mean, rstd, dn, dh, G[p + ".norm.weight"], G[p + ".norm.bias"], dx_beta=1.0)
+
+    def _attn_bwd(self, dh, p, saved):
+        cfg, P, G = self.config, self.P, self.G
+        h, mean, rstd, n, qkv, S, O = saved
+        H, D = cfg["n_heads"], cfg["head_dim"]
+        HD = H * D
+        B, T, _ = h.shape
+        scale = 1.0 / math.sqrt(D)
+        dO = self._lin_bwd(dh, O, p + ".out.weight", p + ".out.bias")
+        dqkv = torch.empty_like(qkv)
+        sS, sQ, sO = (H * T * T, T * T), (T * 3 * HD, D), (T * HD, D)
+        # dV = P^T dO
+        ops.gemm(S, dO, dqkv, trans_a=True, M=T, N=D, K=T, lda=T, ldb=HD, ldc=3 * HD, nb1=B, nb2=H, sa=sS, sb=sO, sc=sQ,
+                 c_off=2 * HD)
+        # dP = dO V^T, then dS = softmax_bwd in place
+        dP = torch.empty_like(S)
+        ops.gemm(dO, qkv, dP, trans_b=True, M=T, N=T, K=D, lda=HD, ldb=3 * HD, ldc=T, nb1=B, nb2=H, sa=sO, sb=sQ, sc=sS,
+                 b_off=2 * HD)
+        ops.softmax_bwd(S, dP, out=dP, scale=1.0)
+        # dQ = scale * dS K ;  dK = scale * dS^T Q
+        ops.gemm(dP, qkv, dqkv, M=T, N=D, K=T, lda=T, ldb=3 * HD, ldc=3 * HD, nb1=B, nb2=H, sa=sS, sb=sQ, sc=sQ, b_off=HD,
+                 c_off=0, alpha=scale)
+        ops.gemm(dP, qkv, dqkv, trans_a=True, M=T, N=D, K=T, lda=T, ldb=3 * HD, ldc=3 * HD, nb1=B, nb2=H, sa=sS, sb=sQ,
+                 sc=sQ, b_off=0, c_off=HD, alpha=scale)
+        cos, sin = self._rotary(T)
+        ops.rotary(dqkv, cos, sin, B, T, 2 * H, D, 3 * HD, inverse=True)
+        dn = self._lin_bwd(dqkv, n, p + ".qkv.weight", p + ".qkv.bias")
+        ops.layernorm_bwd(h, P[p + ".norm.weight"], mean, rstd, dn, dh, G[p + ".norm.weight"], G[p + ".norm.bias"], dx_beta=1.0)
+
+    def _conv_bwd(self, dh, p, saved):
+        cfg, P, G = self.config, self.P, self.G
+        h, mean, rstd, n, u, g, c, stats, nn_, s = saved
+        ds = self._lin_bwd(dh, s, p + ".pw2.weight", p + ".pw2.bias")
+        dnn = ops.silu_bwd(nn_, ds, out=ds)
+        dc = torch.empty_like(c)
+        if cfg["conv_norm"] == "rms_norm":
+            ops.rmsnorm_bwd(c, P[p + ".cnorm.weight"], stats[1], dnn, dc, G[p + ".cnorm.weight"], dx_beta=0.0)
+        else:
+            ops.layernorm_bwd(c, P[p + ".cnorm.weight"], stats[0], stats[1], dnn, dc, G[p + ".cnorm.weight"],
+                              G[p + ".cnorm.bias"], dx_beta=0.0)
+        if self.trainable(p + ".dw.weight"):
+            ops.dwconv1d_wgrad(g, dc, G[p + ".dw.weight"], G[p + ".dw.bias"], beta=1.0)
+        dg = ops.dwconv1d_dgrad(dc, P[p + ".dw.weight"])
+        du = ops.glu_bwd(u, dg)
+        dn = self._lin_bwd(du, n, p + ".pw1.weight", p + ".pw1.bias")
+        ops.layernorm_bwd(h, P[p + ".norm.weight"], mean, rstd, dn, dh, G[p + ".norm.weight"], G[p + ".norm.bias"], dx_beta=1.0)
+
+    def _sub_bwd(self, dh, ctx):
+        if not self.trainable("subsampling."):
+            return
+        P, G = self.P, self.G
+        xt, z1, u2, z2, u3, z3, a3 = ctx["sub"]
+        B, T, T3, F3 = ctx["dims"]
+        C = self.config["subsampling_conv_channels"]
+        da3 = self._lin_bwd(dh, a3.view(B, T3, F3 * C), "subsampling.out.weight", "subsampling.out.bias")
+        dz3 = ops.silu_bwd(z3, da3.view_as(z3), out=da3.view_as(z3))
+        du3 = self._lin_bwd(dz3, u3, "subsampling.pw3.weight", "subsampling.pw3.bias")
+        ops.dwconv2d_s2_wgrad(z2, du3, G["subsampling.dw3.weight"], G["subsampling.dw3.bias"], beta=1.0)
+        dz2 = ops.dwconv2d_s2_dgrad(z2, P["subsampling.dw3.weight"], du3)
+        du2 = self._lin_bwd(dz2, u2, "subsampling.pw2.weight", "subsampling.pw2.bias")
+        ops.dwconv2d_s2_wgrad(z1, du2, G["subsampling.dw2.weight"], G["subsampling.dw2.bias"], beta=1.0)
+        dz1 = ops.dwconv2d_s2_dgrad(z1, P["subsampling.dw2.weight"], du2)
+        ops.conv2d_first_wgrad(xt, dz1, G["subsampling.conv1.weight"], G["subsampling.conv1.bias"], beta=1.0)

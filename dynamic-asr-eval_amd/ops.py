@@ -41,6 +41,14 @@ def _cc(t, name, dtype=F32):
     return t
 
 
+def _c(t, name, dtype=F32):
+    """Contiguous but not necessarily 16-byte aligned (kernels with scalar accesses only)."""
+    _chk(t, name, dtype)
+    if not t.is_contiguous():
+        raise DynError(f"{name}: expected a contiguous tensor")
+    return t
+
+
 def _opt(t, name, dtype=F32):
     return 0 if t is None else _cc(t, name, dtype).data_ptr()
 
@@ -176,6 +184,15 @@ def specaug_freqmask(x, f0, width, value=0.0):
     F, T = x.shape
     check(_L().dyn_specaug_freqmask(x.data_ptr(), F, T, f0.data_ptr(), width.data_ptr(), f0.numel(), value, _stream()),
           "dyn_specaug_freqmask")
+    return x
+
+
+def specaug_timemask(x, t0, width, value=0.0):
+    """In-place time masks on a contiguous [F, T] window."""
+    _cc(x, "specaug.x"); _cc(t0, "specaug.t0", I32); _cc(width, "specaug.width", I32)
+    F, T = x.shape
+    check(_L().dyn_specaug_timemask(x.data_ptr(), F, T, t0.data_ptr(), width.data_ptr(), t0.numel(), value, _stream()),
+          "dyn_specaug_timemask")
     return x
 
 
@@ -358,7 +375,7 @@ def rotary(x, cos, sin, B, T, n_heads, D, row_stride, inverse=False):
 def ctc_greedy(log_probs, blank):
     """log_probs [B, T, C] (or [T, C]) on device -> (ids int32 [B, T] device, lengths int32 [B] device).
     Only out_len[b] leading ids of each row are valid."""
-    _cc(log_probs, "ctc_greedy.log_probs")
+    _c(log_probs, "ctc_greedy.log_probs")
     lp = log_probs if log_probs.dim() == 3 else log_probs.unsqueeze(0)
     B, T, C = lp.shape
     arg = torch.empty(B, T, device=lp.device, dtype=I32)
@@ -372,7 +389,7 @@ def ctc_greedy(log_probs, blank):
 def ctc_loss(log_probs, targets, input_lengths, target_lengths, blank, reduction="sum", grad_scale=1.0, want_grad=True):
     """log_probs [B, T, C] contiguous; targets int32 [B, S_max]; lengths int32 [B] (all on device).
     Returns (loss [1] device tensor, nll [B], grad [B, T, C] or None) with torch.nn.CTCLoss semantics."""
-    _cc(log_probs, "ctc_loss.log_probs"); _cc(targets, "ctc_loss.targets", I32)
+    _c(log_probs, "ctc_loss.log_probs"); _c(targets, "ctc_loss.targets", I32)
     _cc(input_lengths, "ctc_loss.input_lengths", I32); _cc(target_lengths, "ctc_loss.target_lengths", I32)
     B, T, C = log_probs.shape
     S_max = targets.shape[1] if targets.numel() else 0
@@ -417,7 +434,7 @@ def clip_grad_norm(g, max_norm):
 
 
 def stitch_accumulate(log_probs, acc, count, pos):
-    _cc(log_probs, "stitch.log_probs"); _cc(acc, "stitch.acc"); _cc(count, "stitch.count")
+    _c(log_probs, "stitch.log_probs"); _cc(acc, "stitch.acc"); _cc(count, "stitch.count")
     rows, C = log_probs.shape
     check(_L().dyn_stitch_accumulate(log_probs.data_ptr(), C, acc.data_ptr(), count.data_ptr(), pos, rows, C, acc.shape[0],
                                      _stream()), "dyn_stitch_accumulate")

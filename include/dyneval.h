@@ -138,6 +138,8 @@ int dyn_rotary(float* x, const float* cos_table, const float* sin_table, int64_t
  * drawn on the host so the RNG stream stays the caller's). */
 int dyn_specaug_freqmask(float* x, int64_t F, int64_t T, const int32_t* f0, const int32_t* width, int64_t n_masks,
                          float value, void* stream);
+int dyn_specaug_timemask(float* x, int64_t F, int64_t T, const int32_t* t0, const int32_t* width, int64_t n_masks,
+                         float value, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CTC.  dyn_ctc_greedy replaces GreedyCTCDecoder on a CPU copy of the posteriors (reference lcasr/lib.py:498,

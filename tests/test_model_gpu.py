@@ -1,0 +1,128 @@
+"""Model-level and loop-level parity on the GPU: the HIP SCConformerXL (forward, backward, adaptation step, dynamic
+eval) against the CPU oracle (oracle/conformer_ref.py, oracle/dynamic_eval_ref.py) with the SAME seeded weights,
+inputs and SpecAugment masks.  Bars from BASELINE.json: CTC argmax token ids bit-exact, adapted logits within 1e-3."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(n_layers=2, d_model=256, n_heads=2, head_dim=128, subsampling_conv_channels=64)
+
+
+def _pair(cuda, cfg, vocab, seed=3, blank_bias=0.0):
+    from oracle.conformer_ref import SCConformerXLRef
+    from dynamic_asr_eval_amd.model import SCConformerXL
+    ref = SCConformerXLRef(cfg, vocab_size=vocab, seed=seed, blank_bias=blank_bias)
+    hip = SCConformerXL(cfg, vocab_size=vocab, device=cuda)
+    assert [n for n, _ in ref.named_parameters()] == [n for n, _ in hip.named_parameters()]
+    hip.load_state_dict(ref.state_dict())
+    return ref, hip
+
+
+@pytest.mark.parametrize("cfg_over,T", [({}, 256), (dict(conv_norm="layer_norm"), 200), (dict(self_conditioning=False), 77)])
+def test_forward_backward_parity(cuda, cfg_over, T):
+    cfg = dict(SMALL, **cfg_over)
+    ref, hip = _pair(cuda, cfg, vocab=128)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 80, T, generator=g)
+    out_ref = ref(audio_signal=x)['final_posteriors']
+    out = hip(audio_signal=x.to(cuda))['final_posteriors']
+    assert out.shape == out_ref.shape
+    err = (out.cpu() - out_ref).abs().max().item()
+    assert err < 2e-4, f"forward log-probs differ by {err}"          # fp32 vs fp32, different summation orders
+    assert torch.equal(out.cpu().argmax(-1), out_ref.argmax(-1))       # argmax ids bit-exact
+    gp = torch.randn(out_ref.shape, generator=g) / out_ref.numel()
+    out_ref.backward(gp)
+    hip.zero_grad()
+    hip.backward(gp.to(cuda))
+    worst = 0.0
+    for (n, p), gh in zip(ref.named_parameters(), hip.grads()):
+        denom = p.grad.abs().max().item() + 1e-12
+        rel = (gh.cpu() - p.grad).abs().max().item() / denom
+        worst = max(worst, rel)
+        assert rel < 2e-3, f"grad {n}: rel err {rel}"
+    print("worst relative grad error", worst)
+
+
+def test_backward_active_subset_matches_full(cuda):
+    """Skipping the clean copy (zero gradient) must give the same parameter gradients as the full backward."""
+    ref, hip = _pair(cuda, SMALL, vocab=128)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 80, 160, generator=g).to(cuda)
+    out = hip(audio_signal=x)['final_posteriors']
+    gp = torch.zeros_like(out)
+    gp[0] = torch.randn(out.shape[1:], generator=g).to(cuda) / out[0].numel()
+    hip.zero_grad(); hip.backward(gp)
+    full = hip.flat_grads.clone()
+    hip(audio_signal=x)
+    hip.zero_grad(); hip.backward(gp[:1].contiguous(), n_active=1)
+    denom = full.abs().max().item()
+    assert (hip.flat_grads - full).abs().max().item() / denom < 1e-5
+
+
+def _args(**kw):
+    a = argparse.Namespace()
+    a.config = {'model': {'subsampling_factor': 8}, 'audio_chunking': {'size': 16384, 'overlap': 0}, 'training': {}}
+    a.__dict__.update(kw)
+    return a
+
+
+def _masks_for(keys, F, u_lens, seed):
+    from oracle.dynamic_eval_ref import draw_masks
+    g = torch.Generator().manual_seed(seed)
+    return {k: (draw_masks(3, 12, F, g), ([], [])) for k in keys}
+
+
+@pytest.mark.parametrize("online,optim_name", [(True, "madgrad"), (False, "madgrad"), (False, "adam")])
+def test_dynamic_eval_parity(cuda, online, optim_name):
+    from oracle import dynamic_eval_ref as R
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    vocab = 128
+    ref, hip = _pair(cuda, SMALL, vocab=vocab, seed=5, blank_bias=1.5)
+    tok = SyntheticTokenizer(vocab)
+    g = torch.Generator().manual_seed(11)
+    spec = torch.randn(1, 80, 1500, generator=g)
+    seq_len, overlap = 512, 256
+    _, keys = R.prepare_chunks(spec, seq_len, overlap)
+    masks = _masks_for(keys, 80, None, seed=2)
+    lr = 1e-4
+    if optim_name == "madgrad":
+        ref_opt, hip_opt, lr_args = MADGRAD_REF, lib.MADGRAD, {'lr': lr}
+    else:
+        ref_opt, hip_opt, lr_args = torch.optim.Adam, lib.Adam, {'lr': lr}
+    before = hip.flat_params.clone()
+    out_ref, params_ref = R.dynamic_eval_ref(ref, spec, seq_len, overlap, tok, ref_opt, lr_args, {}, epochs=1, shuffle=False,
+                                             online=online, fixed_masks=masks, return_params=True)
+    args = _args(optim_lr=lr, epochs=1, shuffle=False, online=online, spec_augment_fixed_masks=masks, quiet=True)
+    out, params = lib.dynamic_eval(args, hip, spec, seq_len, overlap, tok, use_tqdm=False, optim=hip_opt, return_params=True)
+    assert isinstance(out, np.ndarray) and out.dtype == np.float32 and out.shape == out_ref.shape
+    assert torch.equal(hip.flat_params, before), "weights must be restored (reference lib.py:636-637)"
+    err = np.abs(out - out_ref).max()
+    assert err < 1e-3, f"adapted, stitched log-probs differ by {err} (bar: 1e-3 fp32)"
+    assert np.array_equal(out.argmax(-1), out_ref.argmax(-1)), "CTC argmax ids must be bit-exact"
+    # the adaptation really moved the weights, and by the same amount on both sides
+    moved = max((a - b).abs().max().item() for a, b in zip(params_ref, [p.detach() for p in ref.parameters()]))
+    assert moved > 1e-6
+    for a, b in zip(params, params_ref):
+        assert (a - b).abs().max().item() < 5e-5
+
+
+def test_dynamic_eval_short_recording_and_epochs0(cuda):
+    """spec_n <= seq_len -> single window; epochs=0 -> plain forward + stitch (the no-adapt baseline path)."""
+    from oracle import dynamic_eval_ref as R
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    ref, hip = _pair(cuda, SMALL, vocab=128, seed=7, blank_bias=1.0)
+    tok = SyntheticTokenizer(128)
+    spec = torch.randn(1, 80, 300, generator=torch.Generator().manual_seed(4))
+    out_ref = R.dynamic_eval_ref(ref, spec, 512, 256, tok, MADGRAD_REF, {'lr': 1e-4}, {}, epochs=0)
+    out = lib.dynamic_eval(_args(epochs=0, quiet=True), hip, spec, 512, 256, tok, use_tqdm=False)
+    assert out.shape == out_ref.shape
+    assert np.abs(out - out_ref).max() < 2e-4
+    assert np.array_equal(out.argmax(-1), out_ref.argmax(-1))
