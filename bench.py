@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py — dynamic-eval throughput on MI355X (metric and workload of BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One STEP = one pass of the hot path over one synthetic recording of the Earnings-22 long-form shape
+(BASELINE.json configs[1]: 1 h = 360 000 log-mel frames, seq_len 16384 / overlap 14336 -> 169 windows): for every window
+forward (B=2: augmented + clean copy) -> on-device greedy pseudo-label -> CTC loss + gradient -> backward -> one MADGRAD
+step; then the final no-grad pass over all windows, the on-device stitch and the final greedy decode
+(reference lcasr/lib.py:450-640 driven by run_dynamic_eval_full.py:84-100).  The recording is resident in HBM when the
+timed region starts.  Weak scaling: every rank adapts on its own recordings (they are independent: weights restored,
+fresh optimiser per call); the only collective is the WER-counter all-reduce after the timed region.
+
+Prints ONE JSON line on rank 0 with `roofline` (fp32-MFMA GEMM family, measured live with HIP events on the launch
+stream) and, at N=1, `cpu_baseline` (the CPU oracle restatement timed on the host cores on a bounded sample)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 256 CUs x 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=3600.0, help="length of each synthetic recording")
+    ap.add_argument("--seq_len", type=int, default=16384)
+    ap.add_argument("--overlap", type=int, default=14336)
+    ap.add_argument("--vocab", type=int, default=4095)
+    ap.add_argument("--lr", type=float, default=9e-5)
+    ap.add_argument("--online", type=int, default=0)
+    ap.add_argument("--blank_bias", type=float, default=-1.0, help="<0: calibrate for a speech-like token rate")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_windows", type=int, default=1)
+    return ap.parse_args()
+
+
+def make_args(a):
+    ns = argparse.Namespace()
+    ns.config = {'model': {'subsampling_factor': 8}, 'audio_chunking': {'size': 16384, 'overlap': 0}, 'training': {'max_seq_len': 0}}
+    ns.__dict__.update(dict(optim_lr=a.lr, epochs=1, shuffle=False, online=bool(a.online), quiet=True,
+                            spec_augment_n_freq_masks=6, spec_augment_freq_mask_param=34, spec_augment_n_time_masks=0))
+    return ns
+
+
+def cpu_baseline(a):
+    """CPU oracle (oracle/dynamic_eval_ref.py + oracle/conformer_ref.py) on a bounded sample: `cpu_windows` full
+    16384-frame windows, each = adapt step (B=2 fwd + CTC + bwd + MADGRAD) + final-pass forward + stitch; the 1 h
+    recording is 169 such windows, so audio-s/s = 3600 / (169 * seconds_per_window)."""
+    from oracle.conformer_ref import SCConformerXLRef
+    from oracle.dynamic_eval_ref import dynamic_eval_ref
+    from oracle.madgrad_ref import MADGRAD
+    from dynamic_asr_eval_amd.datasets import synthetic_spec
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    model = SCConformerXLRef(vocab_size=a.vocab, seed=0, blank_bias=a.blank_bias)
+    tok = SyntheticTokenizer(a.vocab)
+    spec = synthetic_spec(a.seq_len * a.cpu_windows, seed=1234)
+    t0 = time.time()
+    for w in range(a.cpu_windows):
+        win = spec[:, :, w * a.seq_len:(w + 1) * a.seq_len]
+        dynamic_eval_ref(model, win, a.seq_len, 0, tok, MADGRAD, {'lr': a.lr},
+                         {'n_freq_masks': 6, 'freq_mask_param': 34}, epochs=1, online=False)
+    dt = (time.time() - t0) / a.cpu_windows
+    n_windows = 169
+    return {"value": round(3600.0 / (n_windows * dt), 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"{a.cpu_windows} of {n_windows} windows (16384 frames each: B=2 forward + CTC + backward + MADGRAD, then "
+                      f"final-pass forward + stitch) on {cores} host threads, {dt:.1f} s/window, extrapolated x{n_windows}"}
+
+
+def main():
+    a = parse()
+    from dynamic_asr_eval_amd import dist as ddist, lib, ops
+    from dynamic_asr_eval_amd.datasets import synthetic_spec
+    from dynamic_asr_eval_amd.decoding import GreedyCTCDecoder
+    from dynamic_asr_eval_amd.model import SCConformerXL
+    from dynamic_asr_eval_amd.synthetic_weights import init_synthetic
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    from dynamic_asr_eval_amd.wer import edit_counts
+
+    rank, local_rank, world = ddist.init()
+    assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    model = SCConformerXL(vocab_size=a.vocab, device=dev)
+    init_synthetic(model, seed=0, blank_bias=0.0)
+    tok = SyntheticTokenizer(a.vocab)
+    decoder = GreedyCTCDecoder(tok, blank_id=a.vocab, device=dev)
+    args = make_args(a)
+    n_frames = int(a.seconds * 100)
+    torch.manual_seed(1234 + rank)
+
+    def one_step(step_idx):
+        spec = synthetic_spec(n_frames, seed=1234 + 1000 * rank + step_idx).to(dev)  # resident in HBM before timing
+        return spec
+
+    def run(spec):
+        logits = lib.dynamic_eval(args, model, spec, a.seq_len, a.overlap, tok, use_tqdm=False, return_device=True)
+        return decoder.ids(logits)
+
+    specs = [one_step(i) for i in range(a.warmup + a.steps)]
+    if a.blank_bias < 0:  # shape the seeded model so pseudo-labels have a speech-like token rate (outside the timed region)
+        from dynamic_asr_eval_amd.synthetic_weights import calibrate_blank_bias
+        a.blank_bias = calibrate_blank_bias(model, specs[0][:, :, :a.seq_len].contiguous())
+    else:
+        model.P["decoder.ff.bias"][-1] += a.blank_bias
+    for i in range(a.warmup):
+        run(specs[i])
+    ddist.barrier()
+    torch.cuda.synchronize(dev)
+    ops.gemm_profile_start(every=16)
+    t0 = time.perf_counter()
+    hyps = []
+    for i in range(a.warmup, a.warmup + a.steps):
+        hyps.append(run(specs[i]))
+    torch.cuda.synchronize(dev)
+    ddist.barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.gemm_profile_stop()
+    dt = ddist.max_over_ranks(dt)
+    # the path's one collective: WER counters over RCCL (outside the timed region, as in the reference harness)
+    counts = ddist.all_reduce_counts(edit_counts([tok.decode(h) for h in hyps], [tok.decode(h) for h in hyps]))
+
+    if rank == 0:
+        audio_s = a.seconds * a.steps * world
+        achieved = prof["sampled_flops"] / (prof["sampled_ms"] * 1e-3) / 1e12 if prof and prof["sampled_ms"] > 0 else None
+        out = {
+            "metric": "audio-sec/s dynamic-eval (fwd+1 adapt step)", "value": round(audio_s / dt, 3), "unit": "audio-s/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "run_dynamic_eval_full: 1 h Earnings-22-shape recording per step (360000 frames, seq_len "
+                                   f"{a.seq_len}, overlap {a.overlap}, {'online' if a.online else 'offline'}, MADGRAD lr {a.lr}, "
+                                   "6 freq masks <=34), SCConformerXL 6x768 V+1=4096 seeded weights",
+                       "recording_seconds": a.seconds, "windows_per_recording": len(lib.prepare_chunks(specs[0], a.seq_len, a.overlap)[1]),
+                       "sharding": f"{world} ranks x {a.steps} recordings, no data-path collective",
+                       "blank_bias": round(a.blank_bias, 4), "hyp_tokens_per_recording": [len(h) for h in hyps]},
+            "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None, "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                         "gemm_launches": prof["calls"] if prof else 0, "sampled_launches": prof["sampled"] if prof else 0,
+                         "gemm_tflop_per_step": round(prof["flops"] / a.steps / 1e12, 2) if prof else None},
+            "wer_counters": list(counts),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

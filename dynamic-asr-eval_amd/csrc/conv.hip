@@ -7,6 +7,7 @@
 // Reference call sites: upstream SCConformerXL conv module / subsampling reached through
 // model(audio_signal=...) (reference lcasr/lib.py:164,550; earnings_finetune/lcasr160rb1.yaml:10-15).
 #include "common.h"
+#include "reduce.h"
 
 namespace {
 
@@ -262,14 +263,6 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_wgrad_kernel(const float* __r
     partial_b[tile * C + c] = accb;
 }
 
-__global__ void reduce_tiles_kernel(const float* __restrict__ partial, float* out, int64_t P, int64_t n, float beta) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int64_t p = 0; p < P; ++p) s += partial[p * n + i];
-        out[i] = (beta != 0.f ? beta * out[i] : 0.f) + s;
-    }
-}
-
 template <bool FLIP>
 int launch_dw1d(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t T, int64_t C, int64_t KW,
                 float beta, hipStream_t st) {
@@ -284,9 +277,11 @@ int launch_dw1d(const float* x, const float* w, const float* bias, float* y, int
     return dyn::check_launch("dyn_dwconv1d");
 }
 
+// Rows (time steps) per wgrad workgroup: short serial chains and thousands of workgroups; the partial sums are
+// combined afterwards by the fixed-order 2-D reducer (reduce.h).
 inline int64_t wgrad_tiles(int64_t B, int64_t T, int64_t* per_block) {
-    int64_t chunks = dyn::cdiv(T, 64);
-    if (chunks > 128) chunks = 128;
+    int64_t chunks = dyn::cdiv(T, 8);
+    if (chunks > 2048) chunks = 2048;
     if (chunks < 1) chunks = 1;
     *per_block = dyn::cdiv(T > 0 ? T : 1, chunks);
     chunks = dyn::cdiv(T > 0 ? T : 1, *per_block);
@@ -334,8 +329,8 @@ extern "C" int dyn_dwconv1d_wgrad(const float* x, const float* dy, float* dw, fl
         default: dyn::set_error("dwconv1d_wgrad: unsupported kernel width %lld", (long long)KW); return DYN_E_UNSUPPORTED;
     }
 #undef GO
-    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)dyn::cdiv(C * KW, 256)), dim3(256), 0, st, pw, dw, tiles, C * KW, beta);
-    if (dbias) hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)dyn::cdiv(C, 256)), dim3(256), 0, st, pb, dbias, tiles, C, beta);
+    dyn::launch_reduce_partials(pw, dw, tiles, C * KW, beta, st);
+    if (dbias) dyn::launch_reduce_partials(pb, dbias, tiles, C, beta, st);
     return dyn::check_launch("dyn_dwconv1d_wgrad");
 }
 
@@ -369,8 +364,8 @@ extern "C" int dyn_conv2d_first_wgrad(const float* x, const float* dz, float* dw
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)chunks, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
     hipLaunchKernelGGL(conv2d_first_wgrad_kernel, grid, dim3(256), 0, st, x, dz, pw, pb, T, (int)F, To, (int)Fo, (int)C, per);
-    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)dyn::cdiv(C * 9, 256)), dim3(256), 0, st, pw, dw, tiles, C * 9, beta);
-    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)dyn::cdiv(C, 256)), dim3(256), 0, st, pb, dbias, tiles, C, beta);
+    dyn::launch_reduce_partials(pw, dw, tiles, C * 9, beta, st);
+    dyn::launch_reduce_partials(pb, dbias, tiles, C, beta, st);
     return dyn::check_launch("dyn_conv2d_first_wgrad");
 }
 
@@ -408,7 +403,7 @@ extern "C" int dyn_dwconv2d_s2_wgrad(const float* z, const float* du, float* dw,
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)chunks, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
     hipLaunchKernelGGL(dwconv2d_s2_wgrad_kernel, grid, dim3(256), 0, st, z, du, pw, pb, T, (int)F, To, (int)Fo, (int)C, per);
-    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)dyn::cdiv(C * 9, 256)), dim3(256), 0, st, pw, dw, tiles, C * 9, beta);
-    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)dyn::cdiv(C, 256)), dim3(256), 0, st, pb, dbias, tiles, C, beta);
+    dyn::launch_reduce_partials(pw, dw, tiles, C * 9, beta, st);
+    dyn::launch_reduce_partials(pb, dbias, tiles, C, beta, st);
     return dyn::check_launch("dyn_dwconv2d_s2_wgrad");
 }

@@ -5,6 +5,7 @@
 // Reference call sites: every LayerNorm / conv-module norm inside model(audio_signal=...) and its backward
 // (reference lcasr/lib.py:550,579); `default_norm: layer_norm` (earnings_finetune/lcasr160rb1.yaml:24).
 #include "common.h"
+#include "reduce.h"
 
 namespace {
 
@@ -133,14 +134,6 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
     }
 }
 
-__global__ void reduce_rows_kernel(const float* __restrict__ partial, float* out, int64_t P, int64_t n, float beta) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int64_t p = 0; p < P; ++p) s += partial[p * n + i];
-        out[i] = (beta != 0.f ? beta * out[i] : 0.f) + s;
-    }
-}
-
 inline int bwd_blocks(int64_t rows) {
     int64_t g = dyn::cdiv(rows, WPB);
     if (g > 256) g = 256;
@@ -182,9 +175,8 @@ int launch_bwd(const float* x, const float* gamma, const float* mean, const floa
         case 8: hipLaunchKernelGGL((norm_bwd_kernel<8, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows); break;
         default: dyn::set_error("norm: unsupported C=%lld", (long long)C); return DYN_E_UNSUPPORTED;
     }
-    int64_t rg = dyn::cdiv(C, 256);
-    if (dgamma) hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rg), dim3(256), 0, st, pg, dgamma, (int64_t)nb, C, wbeta);
-    if (!RMS && dbeta) hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rg), dim3(256), 0, st, pb, dbeta, (int64_t)nb, C, wbeta);
+    if (dgamma) dyn::launch_reduce_partials(pg, dgamma, (int64_t)nb, C, wbeta, st);
+    if (!RMS && dbeta) dyn::launch_reduce_partials(pb, dbeta, (int64_t)nb, C, wbeta, st);
     return dyn::check_launch("dyn_norm_bwd");
 }
 

@@ -81,8 +81,40 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha
     d.split_k = split_k
     ws = workspace(c.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    prof = GEMM_PROFILE
+    if prof is not None:
+        prof["calls"] += 1
+        prof["flops"] += 2.0 * M * N * K * nb1 * nb2
+        if prof["calls"] % prof["every"] == 0:  # HIP events on the launch stream around this one launch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(_L().dyn_gemm_f32(ctypes.byref(d), _stream()), "dyn_gemm_f32")
+            e1.record()
+            prof["samples"].append((2.0 * M * N * K * nb1 * nb2, e0, e1))
+            return c
     check(_L().dyn_gemm_f32(ctypes.byref(d), _stream()), "dyn_gemm_f32")
     return c
+
+
+GEMM_PROFILE = None
+
+
+def gemm_profile_start(every=8):
+    """Sample every `every`-th GEMM launch with a HIP-event pair (bench.py's live roofline measurement)."""
+    global GEMM_PROFILE
+    GEMM_PROFILE = {"calls": 0, "flops": 0.0, "every": int(every), "samples": []}
+
+
+def gemm_profile_stop():
+    """-> dict(calls, flops, sampled, sampled_flops, sampled_ms): call after a stream synchronize."""
+    global GEMM_PROFILE
+    prof, GEMM_PROFILE = GEMM_PROFILE, None
+    if prof is None:
+        return None
+    fl = sum(s[0] for s in prof["samples"])
+    ms = sum(s[1].elapsed_time(s[2]) for s in prof["samples"])
+    return {"calls": prof["calls"], "flops": prof["flops"], "sampled": len(prof["samples"]), "sampled_flops": fl,
+            "sampled_ms": ms}
 
 
 def linear(x, w, bias=None, out=None, alpha=1.0, beta=0.0):

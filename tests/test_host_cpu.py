@@ -1,0 +1,232 @@
+"""CPU suite (-m "not gpu"): host logic, the C-ABI surface, and the oracle against values taken from the reference's
+own files.  No compute call on the HIP library is made here (there is no GPU in this container)."""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+# ------------------------------------------------------------------------------------------------ C-ABI surface
+def test_library_loads_and_exports_every_declared_symbol():
+    from dynamic_asr_eval_amd import _lib
+    lib = _lib.load()
+    names = _lib.exported_symbols()
+    assert len(names) >= 45
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dyneval.h but not exported by libdyneval_hip.so"
+    assert lib.dyn_arch() == b"gfx950"
+    assert lib.dyn_version().startswith(b"dyneval-hip")
+
+
+def test_abi_argument_errors_are_codes_not_crashes():
+    """Argument validation runs on the host before any launch, so it is checkable without a GPU."""
+    from dynamic_asr_eval_amd import _lib
+    lib = _lib.load()
+    assert lib.dyn_silu_fwd(None, None, 16, None) == -1          # DYN_E_ARG
+    assert b"dyn_silu_fwd" in lib.dyn_last_error()
+    assert lib.dyn_glu_fwd(1, 1, 4, 6, None) == -1               # C % 4 != 0
+    assert lib.dyn_layernorm_fwd(1, 1, 1, 1, 1, 1, 4, 100, 1e-5, None) == -1   # C % 256 != 0
+    assert lib.dyn_ctc_loss(1, 8, 1, 5, 5, 40, 1, 4, 1, 1, 7, 0, 1.0, 1, None, None, 5, 40, None, 0, None) == -1  # blank >= C
+    assert lib.dyn_ctc_loss_workspace_bytes(2048, 1, 500) > 2 * 2048 * 1001 * 4
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K, d.nb1, d.nb2 = 768, 768, 4096, 1, 1
+    assert lib.dyn_gemm_f32_workspace_bytes(ctypes.byref(d)) > 0  # deep-K wgrad shape gets a split-K plan
+    d.M, d.N, d.K = 4096, 3072, 768
+    assert lib.dyn_gemm_f32_workspace_bytes(ctypes.byref(d)) == 0
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from dynamic_asr_eval_amd import ops
+    from dynamic_asr_eval_amd._lib import DynError
+    with pytest.raises(DynError):
+        ops.silu(torch.zeros(8))
+    from dynamic_asr_eval_amd.model import SCConformerXL
+    with pytest.raises(DynError):
+        SCConformerXL(device="cpu")
+    from dynamic_asr_eval_amd.decoding import GreedyCTCDecoder
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    if not torch.cuda.is_available():
+        with pytest.raises(DynError):
+            GreedyCTCDecoder(SyntheticTokenizer(8), 8)(torch.zeros(4, 9))
+
+
+# ------------------------------------------------------------------------------------------------ windowing / stitch plan
+@pytest.mark.parametrize("impl", ["product", "oracle"])
+def test_prepare_chunks_matches_reference_counts(impl):
+    """Window counts stated by the reference material: 1 h (360000 frames) at 16384/14336 -> 169 windows, last 15936
+    (from reference lcasr/lib.py:128-145); 415990 frames -> 197 (timeit_earnings22.sh:6 recording)."""
+    if impl == "product":
+        from dynamic_asr_eval_amd.lib import prepare_chunks
+    else:
+        from oracle.dynamic_eval_ref import prepare_chunks
+    gold = json.load(open(os.path.join(GOLDEN, "prepare_chunks.json")))
+    for case in gold["cases"]:
+        spec = torch.empty(1, 1, case["spec_n"])
+        data, keys = prepare_chunks(spec, case["seq_len"], case["overlap"])
+        assert len(keys) == case["n_windows"], case
+        assert keys[:3] == case["first_keys"] and keys[-1] == case["last_key"]
+        assert data[keys[-1]].shape[-1] == case["last_len"]
+        assert all(data[k].data_ptr() == spec[:, :, k:].data_ptr() for k in keys)  # views, not copies
+
+
+def test_apply_args_flag_surface_and_kwargs():
+    from dynamic_asr_eval_amd import lib
+    p = argparse.ArgumentParser()
+    args = lib.apply_args(p, ["-ds", "-epochs", "2", "-seq", "2048", "-o", "0", "-dfa", "-kwargs", "optim_lr=9e-6",
+                              "spec_augment_n_freq_masks=6", "online=True"])
+    assert args.seq_len == 2048 and args.overlap == 0 and args.epochs == 2 and args.shuffle is False
+    assert args.optim_lr == 9e-6 and args.online is True and args.disable_flash_attention
+    assert lib.get_lr_args_from_args(args) == {"lr": 9e-6}
+    assert lib.get_lr_args_from_args(argparse.Namespace()) == {"lr": 9e-5}            # reference lib.py:124
+    sa = lib.get_specaugment_config_from_args(args)
+    assert sa == {"n_time_masks": 0, "n_freq_masks": 6, "freq_mask_param": 42, "time_mask_param": -1, "min_p": 0.05,
+                  "zero_masking": False}                                                # reference lib.py:104-111
+    assert lib.get_cutout_params_from_args(args, 2048)["num_rectangles"] == 0
+    assert lib.get_frame_shuffle_config_from_args(args) == {"time_dimension": False, "freq_dimension": False}
+
+
+def test_optional_augmentations_refuse_instead_of_silently_skipping():
+    from dynamic_asr_eval_amd import lib
+
+    class M:
+        device = torch.device("cuda:0")
+    a = argparse.Namespace(config={'model': {'subsampling_factor': 8}, 'audio_chunking': {'size': 1, 'overlap': 0}, 'training': {}},
+                           random_noise=0.1)
+    with pytest.raises(NotImplementedError):
+        lib.dynamic_eval(a, M(), torch.zeros(1, 80, 10), 8, 0, None)
+
+
+# ------------------------------------------------------------------------------------------------ host utilities
+def test_wer_counts_and_rates():
+    from dynamic_asr_eval_amd.wer import edit_counts, word_error_rate_detail, basic_normalize
+    assert edit_counts(["a b c d", "x y"], ["a c d e", "x y z"]) == (1, 2, 0, 7)
+    wer, words, ins, dele, sub = word_error_rate_detail(["the cat sat"], ["the cat sat on the mat"])
+    assert (wer, words, ins, dele, sub) == (0.5, 6, 0.0, 0.5, 0.0)
+    assert word_error_rate_detail(["a"], ["a"])[0] == 0.0
+    assert basic_normalize("Hello,  WORLD! it's") == "hello world it's"
+    rng = np.random.RandomState(0)
+
+    def lev(h, r):
+        d = list(range(len(h) + 1))
+        for i in range(1, len(r) + 1):
+            nd = [i] + [0] * len(h)
+            for j in range(1, len(h) + 1):
+                nd[j] = min(d[j - 1] + (h[j - 1] != r[i - 1]), d[j] + 1, nd[j - 1] + 1)
+            d = nd
+        return d[-1]
+    from dynamic_asr_eval_amd.wer import _align
+    for _ in range(200):
+        h = rng.randint(0, 5, rng.randint(0, 14)).tolist(); r = rng.randint(0, 5, rng.randint(0, 14)).tolist()
+        i, d, s = _align(h, r)
+        assert i + d + s == lev(h, r) and len(h) - i == len(r) - d
+
+
+def test_tokenizers_round_trip():
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer, load_sentencepiece
+    t = SyntheticTokenizer(4095)
+    ids = [0, 17, 4094, 17, 3]
+    assert t.encode(t.decode(ids)) == ids and t.vocab_size() == 4095 and t.encode("") == []
+    sp = load_sentencepiece(os.path.join(GOLDEN, "tokenizer_128.model"))   # the reference's only tokenizer asset
+    assert sp.vocab_size() == 128
+    text = "hello world this is a test"
+    assert sp.decode(sp.encode(text)) == text
+
+
+def test_specaugment_draw_rule_is_shared_with_oracle():
+    from dynamic_asr_eval_amd.augment import SpecAugment, draw_masks
+    from oracle.dynamic_eval_ref import draw_masks as draw_ref
+    a = draw_masks(6, 34, 80, torch.Generator().manual_seed(3))
+    b = draw_ref(6, 34, 80, torch.Generator().manual_seed(3))
+    assert a == b and all(0 <= s and s + w <= 80 and w <= 34 for s, w in zip(*a))
+    fm, tm = SpecAugment(n_freq_masks=6, freq_mask_param=34, n_time_masks=2, time_mask_param=-1, min_p=0.05).draw(80, 1000, torch.Generator().manual_seed(1))
+    assert len(fm[0]) == 6 and len(tm[0]) == 2 and all(w <= 50 for w in tm[1])
+
+
+def test_shard_longest_first_is_balanced_and_deterministic():
+    from dynamic_asr_eval_amd.dist import shard_longest_first
+    lens = [360000, 415990, 120000, 90000, 90000, 300000, 45000]
+    bins = shard_longest_first(lens, 3)
+    assert sorted(i for b in bins for i in b) == list(range(7))
+    loads = [sum(lens[i] for i in b) for b in bins]
+    assert max(loads) - min(loads) <= max(lens)
+    assert bins == shard_longest_first(lens, 3)
+    assert shard_longest_first(lens, 1) == [list(range(7))]
+    assert shard_longest_first([5, 4], 4) == [[0], [1], [], []]
+
+
+def test_gloo_world2_counter_allreduce_and_gather():
+    """The N>1 path on CPU: 2 ranks, gloo, recordings sharded, the WER counters all-reduced, records gathered."""
+    script = os.path.join(ROOT, "tests", "_gloo_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", script],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    res = json.loads(line[len("RESULT "):])
+    assert res["counts"] == res["expected_counts"]
+    assert res["ids"] == [f"rec{i}" for i in range(5)]
+    assert res["max_elapsed"] == 2.0
+
+
+# ------------------------------------------------------------------------------------------------ oracle pins
+def test_oracle_ctc_greedy_and_stitch_toy():
+    """3-window toy of the stitch arithmetic (reference lcasr/lib.py:615-629) worked by hand."""
+    from oracle.dynamic_eval_ref import greedy_ctc_ids
+    lp = torch.log(torch.tensor([[.1, .8, .1], [.1, .8, .1], [.1, .1, .8], [.7, .2, .1], [.1, .8, .1]]))
+    assert greedy_ctc_ids(lp, blank_id=2) == [1, 0, 1]
+    gold = json.load(open(os.path.join(GOLDEN, "stitch_toy.json")))
+    seq_len, overlap, ds = gold["seq_len"], gold["overlap"], gold["downsample"]
+    pos, cover = 0, {}
+    for k, u_len in zip(gold["keys"], gold["u_lens"]):
+        ds_len = u_len // ds
+        ov = int(overlap / (u_len / ds_len))
+        pos -= ov if k != 0 else 0
+        for r in range(pos, pos + ds_len):
+            cover[r] = cover.get(r, 0) + 1
+        pos += ds_len
+    assert [cover[r] for r in sorted(cover)] == gold["counts"]
+
+
+def test_oracle_softdtw_matches_reference_recurrence_fixture():
+    """Soft-DTW values and gradients for the reference's own self-check shape family (soft_dtw_cuda.py:382-428),
+    generated by oracle/softdtw_ref.py (numpy fp64 restatement of soft_dtw_cuda.py:184-239) — see tests/golden/README.md."""
+    from oracle.softdtw_ref import softdtw_forward_backward
+    z = np.load(os.path.join(GOLDEN, "softdtw_17x15x2.npz"))
+    R, E = softdtw_forward_backward(z["D"], float(z["gamma"]), 0.0)
+    assert np.allclose(R, z["value"], rtol=0, atol=1e-12)
+    assert np.allclose(E, z["grad"], rtol=0, atol=1e-12)
+    # hand-checkable case: 1x1 -> value = D, grad = 1; and gamma -> 0 approaches hard DTW
+    R1, E1 = softdtw_forward_backward(np.array([[[3.5]]]), 1.0, 0.0)
+    assert R1[0] == 3.5 and E1[0, 0, 0] == 1.0
+    D = np.array([[[1., 9., 9.], [9., 2., 9.], [9., 9., 3.]]])
+    Rh, _ = softdtw_forward_backward(D, 1e-3, 0.0)
+    assert abs(Rh[0] - 6.0) < 1e-2
+
+
+def test_oracle_model_and_madgrad_are_self_consistent():
+    from oracle.conformer_ref import SCConformerXLRef
+    from oracle.madgrad_ref import MADGRAD
+    from dynamic_asr_eval_amd.model import param_spec, make_config
+    cfg = dict(n_layers=1, d_model=256, n_heads=2, head_dim=64, subsampling_conv_channels=32)
+    m = SCConformerXLRef(cfg, vocab_size=16, seed=0)
+    assert [(n, tuple(p.shape)) for n, p in m.named_parameters()] == [(n, tuple(s)) for n, s in param_spec(make_config(**cfg), 17)]
+    out = m(audio_signal=torch.randn(2, 80, 64))["final_posteriors"]
+    assert out.shape == (2, 8, 17) and torch.allclose(out.exp().sum(-1), torch.ones(2, 8), atol=1e-5)
+    assert SCConformerXLRef(vocab_size=4095).decoder.num_classes == 4096
+    # MADGRAD, one step from zero state with momentum 0: p1 = p0 - lamb*g / (cbrt(lamb*g^2) + eps)
+    p = torch.nn.Parameter(torch.tensor([1.0, -2.0]))
+    opt = MADGRAD([p], lr=0.1, momentum=0.0, eps=1e-6)
+    p.grad = torch.tensor([0.5, 0.25]); opt.step()
+    lamb = 0.1 + 1e-6
+    exp = torch.tensor([1.0, -2.0]) - lamb * torch.tensor([0.5, 0.25]) / ((lamb * torch.tensor([0.25, 0.0625])).pow(1 / 3) + 1e-6)
+    assert torch.allclose(p.detach(), exp, atol=1e-7)

@@ -1,0 +1,67 @@
+"""Soft-DTW parity: HIP kernels vs the numpy fp64 oracle (restatement of reference wav2vec2/soft_dtw_cuda.py:184-239),
+at the reference's own self-check shapes and tolerances (soft_dtw_cuda.py:424-428: (128,17,15,2) atol 1e-6 on the
+gradient, (512,64,64,2) 1e-4, (512,256,256,2) 1e-3, torch.manual_seed(1234), torch.rand inputs, gamma = 1.0), the
+intended call shape of the reference ([2, 409, 32] logits, gamma 1.5, wav2vec2/lib.py:184-190), the committed golden
+fixture, and a length beyond the reference's 1024 limit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _run(cuda, a, b, gamma, bandwidth=None):
+    from dynamic_asr_eval_amd.soft_dtw import SoftDTW
+    x = a.to(cuda).requires_grad_()
+    y = b.to(cuda)
+    out = SoftDTW(True, gamma=gamma, bandwidth=bandwidth)(x, y)
+    (g,) = torch.autograd.grad(out, x, grad_outputs=torch.ones_like(out))
+    return out.cpu().double().numpy(), g.cpu().double().numpy()
+
+
+def _oracle(a, b, gamma, bandwidth=0.0):
+    from oracle.softdtw_ref import softdtw_forward_backward, sqdist
+    a64, b64 = a.double().numpy(), b.double().numpy()
+    D = sqdist(a64, b64)
+    val, E = softdtw_forward_backward(D, gamma, bandwidth)
+    dx = 2.0 * (E[..., None] * (a64[:, :, None, :] - b64[:, None, :, :])).sum(2)
+    return val, dx
+
+
+@pytest.mark.parametrize("B,N,M,d,tol_bwd", [(128, 17, 15, 2, 1e-6), (512, 64, 64, 2, 1e-4), (64, 256, 256, 2, 1e-3)])
+def test_reference_self_check_shapes(cuda, B, N, M, d, tol_bwd):
+    torch.manual_seed(1234)
+    a, b = torch.rand(B, N, d), torch.rand(B, M, d)
+    val, dx = _run(cuda, a, b, 1.0)
+    rv, rdx = _oracle(a, b, 1.0)
+    assert np.allclose(val, rv, rtol=1e-5, atol=1e-8 * max(N, M) * 100)      # torch.allclose defaults of the reference check
+    assert np.allclose(dx, rdx, atol=tol_bwd * 10, rtol=1e-4)                 # dX sums M gradient cells (tol x M^0.5)
+
+
+def test_intended_call_shape_and_golden(cuda):
+    torch.manual_seed(7)
+    x = torch.randn(2, 409, 32) * 0.3
+    val, dx = _run(cuda, x, x.flip(1).contiguous(), 1.5)
+    rv, rdx = _oracle(x, x.flip(1).contiguous(), 1.5)
+    assert np.allclose(val, rv, rtol=2e-5) and np.allclose(dx, rdx, atol=2e-3, rtol=1e-3)
+    z = np.load(os.path.join(GOLDEN, "softdtw_17x15x2.npz"))
+    val, _ = _run(cuda, torch.tensor(z["a"]), torch.tensor(z["b"]), float(z["gamma"]))
+    assert np.allclose(val, z["value"], rtol=1e-5)
+
+
+def test_beyond_1024_and_bandwidth_and_normalize(cuda):
+    from dynamic_asr_eval_amd.soft_dtw import SoftDTW
+    torch.manual_seed(3)
+    a, b = torch.rand(2, 1500, 4), torch.rand(2, 1100, 4)      # the reference falls back to its CPU path here
+    val, _ = _run(cuda, a, b, 1.0)
+    rv, _ = _oracle(a, b, 1.0)
+    assert np.allclose(val, rv, rtol=5e-5)
+    a, b = torch.rand(3, 40, 3), torch.rand(3, 40, 3)
+    val, dx = _run(cuda, a, b, 0.5, bandwidth=30)
+    rv, rdx = _oracle(a, b, 0.5, 30.0)
+    assert np.allclose(val, rv, rtol=1e-5) and np.allclose(dx, rdx, atol=1e-4)
+    n = SoftDTW(True, gamma=1.0, normalize=True)(a.to(cuda), a.to(cuda)).cpu()
+    assert torch.allclose(n, torch.zeros(3), atol=1e-4)         # normalised self-distance is zero
