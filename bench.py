@@ -67,6 +67,7 @@ def cpu_baseline(a):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, int(os.environ.get("DYN_CPU_BASELINE_THREADS", 16)))  # a 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(cores)
     model = SCConformerXLRef(vocab_size=a.vocab, seed=0, blank_bias=a.blank_bias)
     tok = SyntheticTokenizer(a.vocab)

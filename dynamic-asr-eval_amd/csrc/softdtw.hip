@@ -8,6 +8,10 @@
 // sets the last row/column to -inf, R[N+1,M+1] = R[N,M], E[N+1,M+1] = 1, +-inf cells are reset to -inf) and its
 // Sakoe-Chiba rule (cells with |i - j| > bandwidth > 0 are skipped).
 //
+// Numerics: the lattice (R, and E inside the scan) is kept in fp64 — the reference's CPU path is fp64 too
+// (soft_dtw_cuda.py:189,214) while its CUDA path inherits fp32 from D; at |R| ~ 2e3 an fp32 lattice loses ~1 % of the
+// gradient.  The scan is latency-bound, so fp64 costs bytes (R workspace is 8 B/cell), not time.  D, value, E are fp32.
+//
 // MI355X mapping: one workgroup per sequence pair walks the anti-diagonals; the three live diagonals of R (forward)
 // / E (backward) rotate through LDS so each cell costs 3 LDS reads instead of 3 dependent global loads, one barrier
 // per diagonal.  A thread owns rows i = tid, tid + blockDim, ... so N and M are NOT limited to 1024 (the reference falls
@@ -50,107 +54,108 @@ __global__ __launch_bounds__(TPB) void sqdist_bwd_x_kernel(const float* __restri
     }
 }
 
-__device__ __forceinline__ float softmin3(float r0, float r1, float r2, float gamma, float inv_gamma) {
+__device__ __forceinline__ double softmin3(double r0, double r1, double r2, double gamma) {
     // reference :66-71 — r* are -R/gamma
-    const float rmax = fmaxf(fmaxf(r0, r1), r2);
-    const float rsum = expf(r0 - rmax) + expf(r1 - rmax) + expf(r2 - rmax);
-    return -gamma * (logf(rsum) + rmax);
+    const double rmax = fmax(fmax(r0, r1), r2);
+    const double rsum = exp(r0 - rmax) + exp(r1 - rmax) + exp(r2 - rmax);
+    return -gamma * (log(rsum) + rmax);
 }
 
 // Forward wavefront.  R [B, N+2, M+2] must be pre-filled by the kernel itself (border +inf, R[0,0] = 0).
-__global__ __launch_bounds__(1024) void softdtw_fwd_kernel(const float* __restrict__ D, float* __restrict__ R,
-                                                            float* __restrict__ value, int N, int M, float gamma,
+__global__ __launch_bounds__(1024) void softdtw_fwd_kernel(const float* __restrict__ D, double* __restrict__ R,
+                                                            float* __restrict__ value, int N, int M, float gamma_f,
                                                             float bandwidth) {
-    extern __shared__ __attribute__((aligned(16))) float diag[];  // 3 x (N + 1): R on diagonals p-2, p-1, p by row index i
+    extern __shared__ __attribute__((aligned(16))) double diag[];  // 3 x (N + 1): R on diagonals p-2, p-1, p by row index i
+    const double gamma = (double)gamma_f;
     const int64_t b = blockIdx.x;
     const float* Db = D + b * (int64_t)N * M;
-    float* Rb = R + b * (int64_t)(N + 2) * (M + 2);
+    double* Rb = R + b * (int64_t)(N + 2) * (M + 2);
     const int W = M + 2, LN = N + 1;
-    const float inv_gamma = 1.f / gamma;
+    const double inv_gamma = 1.0 / gamma;
     // initialise R: everything +inf, R[0,0] = 0
     for (int64_t e = threadIdx.x; e < (int64_t)(N + 2) * W; e += blockDim.x) Rb[e] = INFINITY;
-    float* d2 = diag;           // diagonal p-2  (q = i + j, 1-based cells: q = p + 2)
-    float* d1 = diag + LN;      // diagonal p-1
-    float* d0 = diag + 2 * LN;  // diagonal p (being written)
+    double* d2 = diag;           // diagonal p-2  (q = i + j, 1-based cells: q = p + 2)
+    double* d1 = diag + LN;      // diagonal p-1
+    double* d0 = diag + 2 * LN;  // diagonal p (being written)
     // 1-based (i, j); diagonal q = i + j.  q = 0: only R[0,0] = 0; q = 1: R[0,1] = R[1,0] = inf.
     for (int i = threadIdx.x; i <= N; i += blockDim.x) {
-        d2[i] = (i == 0) ? 0.f : INFINITY;  // q = 0: cell (i, -i) exists only for i = 0
-        d1[i] = INFINITY;                   // q = 1
+        d2[i] = (i == 0) ? 0.0 : (double)INFINITY;  // q = 0: cell (i, -i) exists only for i = 0
+        d1[i] = INFINITY;                            // q = 1
     }
     __syncthreads();
-    if (threadIdx.x == 0) Rb[0] = 0.f;
+    if (threadIdx.x == 0) Rb[0] = 0.0;
     for (int q = 2; q <= N + M; ++q) {
         for (int i = threadIdx.x; i <= N; i += blockDim.x) {
             const int j = q - i;
-            float v = INFINITY;
+            double v = INFINITY;
             if (i >= 1 && j >= 1 && j <= M) {
                 if (!(bandwidth > 0.f && fabsf((float)(i - j)) > bandwidth)) {
-                    const float r0 = -d2[i - 1] * inv_gamma;  // R[i-1, j-1]
-                    const float r1 = -d1[i - 1] * inv_gamma;  // R[i-1, j]
-                    const float r2 = -d1[i] * inv_gamma;      // R[i, j-1]
-                    v = Db[(int64_t)(i - 1) * M + (j - 1)] + softmin3(r0, r1, r2, gamma, inv_gamma);
+                    const double r0 = -d2[i - 1] * inv_gamma;  // R[i-1, j-1]
+                    const double r1 = -d1[i - 1] * inv_gamma;  // R[i-1, j]
+                    const double r2 = -d1[i] * inv_gamma;      // R[i, j-1]
+                    v = (double)Db[(int64_t)(i - 1) * M + (j - 1)] + softmin3(r0, r1, r2, gamma);
                     Rb[(int64_t)i * W + j] = v;
                 }
             } else if (i == 0 && j == 0) {
-                v = 0.f;
+                v = 0.0;
             }
             d0[i] = v;
         }
         __syncthreads();
-        float* t = d2; d2 = d1; d1 = d0; d0 = t;
+        double* t = d2; d2 = d1; d1 = d0; d0 = t;
     }
-    if (threadIdx.x == 0) value[b] = Rb[(int64_t)N * W + M];
+    if (threadIdx.x == 0) value[b] = (float)Rb[(int64_t)N * W + M];
 }
 
 // Backward wavefront.  Reads R as left by the forward (finite inside, +inf border), applies the reference's boundary
 // rewrite on the fly, writes E [B, N, M] (gradient of the value w.r.t. D).
-__global__ __launch_bounds__(1024) void softdtw_bwd_kernel(const float* __restrict__ D, const float* __restrict__ R,
+__global__ __launch_bounds__(1024) void softdtw_bwd_kernel(const float* __restrict__ D, const double* __restrict__ R,
                                                             float* __restrict__ E, int N, int M, float gamma, float bandwidth) {
-    extern __shared__ __attribute__((aligned(16))) float diag[];  // 3 x (N + 2): E on diagonals q+2, q+1, q by row index i
+    extern __shared__ __attribute__((aligned(16))) double diag[];  // 3 x (N + 2): E on diagonals q+2, q+1, q by row index i
     const int64_t b = blockIdx.x;
     const float* Db = D + b * (int64_t)N * M;
-    const float* Rb = R + b * (int64_t)(N + 2) * (M + 2);
+    const double* Rb = R + b * (int64_t)(N + 2) * (M + 2);
     float* Eb = E + b * (int64_t)N * M;
     const int W = M + 2, LN = N + 2;
-    const float inv_gamma = 1.f / gamma;
-    const float RNM = Rb[(int64_t)N * W + M];
+    const double inv_gamma = 1.0 / (double)gamma;
+    const double RNM = Rb[(int64_t)N * W + M];
     // R' = R with: last row / column -inf, R'[N+1, M+1] = R[N, M], and +-inf interior cells -> -inf (reference :161-163,:100-101)
-    auto Rv = [&](int i, int j) -> float {
+    auto Rv = [&](int i, int j) -> double {
         if (i == N + 1 && j == M + 1) return RNM;
-        if (i == N + 1 || j == M + 1) return -INFINITY;
-        const float r = Rb[(int64_t)i * W + j];
-        return isinf(r) ? -INFINITY : r;
+        if (i == N + 1 || j == M + 1) return -(double)INFINITY;
+        const double r = Rb[(int64_t)i * W + j];
+        return isinf(r) ? -(double)INFINITY : r;
     };
-    auto Dv = [&](int i, int j) -> float {  // padded D_: zero outside [1..N] x [1..M]
-        return (i >= 1 && i <= N && j >= 1 && j <= M) ? Db[(int64_t)(i - 1) * M + (j - 1)] : 0.f;
+    auto Dv = [&](int i, int j) -> double {  // padded D_: zero outside [1..N] x [1..M]
+        return (i >= 1 && i <= N && j >= 1 && j <= M) ? (double)Db[(int64_t)(i - 1) * M + (j - 1)] : 0.0;
     };
-    float* e2 = diag;           // diagonal q+2
-    float* e1 = diag + LN;      // diagonal q+1
-    float* e0 = diag + 2 * LN;  // diagonal q
+    double* e2 = diag;           // diagonal q+2
+    double* e1 = diag + LN;      // diagonal q+1
+    double* e0 = diag + 2 * LN;  // diagonal q
     // q = N + M + 2 holds only E[N+1, M+1] = 1; q = N + M + 1 holds E[N+1, M] = E[N, M+1] = 0.
     for (int i = threadIdx.x; i <= N + 1; i += blockDim.x) {
-        e2[i] = (i == N + 1) ? 1.f : 0.f;
-        e1[i] = 0.f;
+        e2[i] = (i == N + 1) ? 1.0 : 0.0;
+        e1[i] = 0.0;
     }
     __syncthreads();
     for (int q = N + M; q >= 2; --q) {
         for (int i = threadIdx.x; i <= N + 1; i += blockDim.x) {
             const int j = q - i;
-            float v = 0.f;
+            double v = 0.0;
             if (i >= 1 && i <= N && j >= 1 && j <= M) {
                 if (!(bandwidth > 0.f && fabsf((float)(i - j)) > bandwidth)) {
-                    const float rij = Rv(i, j);
-                    const float a = expf((Rv(i + 1, j) - rij - Dv(i + 1, j)) * inv_gamma);
-                    const float bb = expf((Rv(i, j + 1) - rij - Dv(i, j + 1)) * inv_gamma);
-                    const float c = expf((Rv(i + 1, j + 1) - rij - Dv(i + 1, j + 1)) * inv_gamma);
+                    const double rij = Rv(i, j);
+                    const double a = exp((Rv(i + 1, j) - rij - Dv(i + 1, j)) * inv_gamma);
+                    const double bb = exp((Rv(i, j + 1) - rij - Dv(i, j + 1)) * inv_gamma);
+                    const double c = exp((Rv(i + 1, j + 1) - rij - Dv(i + 1, j + 1)) * inv_gamma);
                     v = e1[i + 1] * a + e1[i] * bb + e2[i + 1] * c;  // E[i+1,j], E[i,j+1], E[i+1,j+1]
                 }
-                Eb[(int64_t)(i - 1) * M + (j - 1)] = v;
+                Eb[(int64_t)(i - 1) * M + (j - 1)] = (float)v;
             }
             e0[i] = v;
         }
         __syncthreads();
-        float* t = e2; e2 = e1; e1 = e0; e0 = t;
+        double* t = e2; e2 = e1; e1 = e0; e0 = t;
     }
 }
 
@@ -180,29 +185,29 @@ extern "C" int dyn_sqdist_bwd_x(const float* x, const float* y, const float* G, 
     return dyn::check_launch("dyn_sqdist_bwd_x");
 }
 
-extern "C" int dyn_softdtw_fwd(const float* D, float* R, float* value, int64_t B, int64_t N, int64_t M, float gamma,
+extern "C" int dyn_softdtw_fwd(const float* D, double* R, float* value, int64_t B, int64_t N, int64_t M, float gamma,
                                float bandwidth, void* stream) {
     DYN_REQUIRE(D && R && value && B >= 0 && N > 0 && M > 0 && gamma > 0.f, DYN_E_ARG, "dyn_softdtw_fwd: bad arguments");
-    DYN_REQUIRE(3 * (N + 2) * 4 <= 160 * 1024 - 1024, DYN_E_UNSUPPORTED, "dyn_softdtw_fwd: N=%lld exceeds the LDS diagonal buffers",
+    DYN_REQUIRE(3 * (N + 2) * 8 <= 160 * 1024 - 1024, DYN_E_UNSUPPORTED, "dyn_softdtw_fwd: N=%lld exceeds the LDS diagonal buffers",
                 (long long)N);
     if (B == 0) return DYN_OK;
-    const size_t shm = (size_t)3 * (N + 1) * sizeof(float);
+    const size_t shm = (size_t)3 * (N + 1) * sizeof(double);
     if (shm > 48 * 1024)
-        hipFuncSetAttribute((const void*)softdtw_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute((const void*)softdtw_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipLaunchKernelGGL(softdtw_fwd_kernel, dim3((unsigned)B), dim3(scan_threads((int)N + 1)), shm, (hipStream_t)stream, D, R, value,
                        (int)N, (int)M, gamma, bandwidth);
     return dyn::check_launch("dyn_softdtw_fwd");
 }
 
-extern "C" int dyn_softdtw_bwd(const float* D, const float* R, float* E, int64_t B, int64_t N, int64_t M, float gamma,
+extern "C" int dyn_softdtw_bwd(const float* D, const double* R, float* E, int64_t B, int64_t N, int64_t M, float gamma,
                                float bandwidth, void* stream) {
     DYN_REQUIRE(D && R && E && B >= 0 && N > 0 && M > 0 && gamma > 0.f, DYN_E_ARG, "dyn_softdtw_bwd: bad arguments");
-    DYN_REQUIRE(3 * (N + 2) * 4 <= 160 * 1024 - 1024, DYN_E_UNSUPPORTED, "dyn_softdtw_bwd: N=%lld exceeds the LDS diagonal buffers",
+    DYN_REQUIRE(3 * (N + 2) * 8 <= 160 * 1024 - 1024, DYN_E_UNSUPPORTED, "dyn_softdtw_bwd: N=%lld exceeds the LDS diagonal buffers",
                 (long long)N);
     if (B == 0) return DYN_OK;
-    const size_t shm = (size_t)3 * (N + 2) * sizeof(float);
+    const size_t shm = (size_t)3 * (N + 2) * sizeof(double);
     if (shm > 48 * 1024)
-        hipFuncSetAttribute((const void*)softdtw_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute((const void*)softdtw_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipLaunchKernelGGL(softdtw_bwd_kernel, dim3((unsigned)B), dim3(scan_threads((int)N + 2)), shm, (hipStream_t)stream, D, R, E, (int)N,
                        (int)M, gamma, bandwidth);
     return dyn::check_launch("dyn_softdtw_bwd");

@@ -30,7 +30,7 @@ def sqdist(x, y):
 def softdtw_forward(D, gamma, bandwidth=0.0):
     D = ops._c(D, "softdtw.D")
     B, N, M = D.shape
-    R = torch.empty(B, N + 2, M + 2, device=D.device, dtype=torch.float32)
+    R = torch.empty(B, N + 2, M + 2, device=D.device, dtype=torch.float64)  # fp64 lattice workspace
     value = torch.empty(B, device=D.device, dtype=torch.float32)
     check(_L().dyn_softdtw_fwd(D.data_ptr(), R.data_ptr(), value.data_ptr(), B, N, M, gamma, bandwidth, _stream()), "dyn_softdtw_fwd")
     return value, R

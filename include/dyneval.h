@@ -186,16 +186,17 @@ int dyn_stitch_finalize(const float* acc, const float* count, float* out, int64_
  * (reference wav2vec2/soft_dtw_cuda.py:33-111), their autograd wrapper (:114-175) and _euclidean_dist_func (:319-329).
  *   dyn_sqdist       D[b,i,j] = sum_k (x[b,i,k] - y[b,j,k])^2            x [B,N,d], y [B,M,d] -> D [B,N,M]
  *   dyn_sqdist_bwd_x dx[b,i,k] = sum_j 2 G[b,i,j] (x[b,i,k] - y[b,j,k])
- *   dyn_softdtw_fwd  R [B,N+2,M+2] (written entirely by the kernel; keep it for the backward), value[b] = R[b,N,M]
+ *   dyn_softdtw_fwd  R [B,N+2,M+2] fp64 lattice workspace (written entirely by the kernel; keep it for the backward),
+ *                    value[b] = R[b,N,M] (fp32)
  *   dyn_softdtw_bwd  E [B,N,M] = d value / d D  (multiply by grad_output on the caller side, as :173-174)
  * bandwidth <= 0 disables the Sakoe-Chiba pruning.  No 1024 limit on N, M (reference :312-314 falls back to CPU).
  * ------------------------------------------------------------------------------------------------ */
 int dyn_sqdist(const float* x, const float* y, float* D, int64_t B, int64_t N, int64_t M, int64_t d, void* stream);
 int dyn_sqdist_bwd_x(const float* x, const float* y, const float* G, float* dx, int64_t B, int64_t N, int64_t M, int64_t d,
                      void* stream);
-int dyn_softdtw_fwd(const float* D, float* R, float* value, int64_t B, int64_t N, int64_t M, float gamma, float bandwidth,
+int dyn_softdtw_fwd(const float* D, double* R, float* value, int64_t B, int64_t N, int64_t M, float gamma, float bandwidth,
                     void* stream);
-int dyn_softdtw_bwd(const float* D, const float* R, float* E, int64_t B, int64_t N, int64_t M, float gamma, float bandwidth,
+int dyn_softdtw_bwd(const float* D, const double* R, float* E, int64_t B, int64_t N, int64_t M, float gamma, float bandwidth,
                     void* stream);
 
 #ifdef __cplusplus

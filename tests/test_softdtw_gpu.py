@@ -19,7 +19,7 @@ def _run(cuda, a, b, gamma, bandwidth=None):
     y = b.to(cuda)
     out = SoftDTW(True, gamma=gamma, bandwidth=bandwidth)(x, y)
     (g,) = torch.autograd.grad(out, x, grad_outputs=torch.ones_like(out))
-    return out.cpu().double().numpy(), g.cpu().double().numpy()
+    return out.detach().cpu().double().numpy(), g.detach().cpu().double().numpy()
 
 
 def _oracle(a, b, gamma, bandwidth=0.0):
