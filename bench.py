@@ -45,6 +45,20 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic():
+    """HBM bytes per gemm_f32_kernel launch from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes of this same command; scripts/pmc_summary.py).  bench.py cannot run the profiler on itself, so this is
+    the latest committed measurement, or null when none exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic.json")))
+    if not files:
+        return None
+    try:
+        return round(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def make_args(a):
     ns = argparse.Namespace()
     ns.config = {'model': {'subsampling_factor': 8}, 'audio_chunking': {'size': 16384, 'overlap': 0}, 'training': {'max_seq_len': 0}}
@@ -152,7 +166,9 @@ def main():
                        "blank_bias": round(a.blank_bias, 4), "hyp_tokens_per_recording": [len(h) for h in hyps]},
             "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                         "traffic": pmc_traffic(), "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                         "algorithmic_bytes_per_launch": round(prof["bytes"] / prof["calls"]) if prof and prof["calls"] else None,
+                         "flop_per_launch": round(prof["flops"] / prof["calls"]) if prof and prof["calls"] else None,
                          "gemm_launches": prof["calls"] if prof else 0, "sampled_launches": prof["sampled"] if prof else 0,
                          "gemm_tflop_per_step": round(prof["flops"] / a.steps / 1e12, 2) if prof else None},
             "wer_counters": list(counts),

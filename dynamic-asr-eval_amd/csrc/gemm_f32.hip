@@ -43,6 +43,25 @@ struct KParams {
 };
 
 // Stage one operand tile (R rows x BK) from HBM into registers.
+// Interior tiles (every row and the whole K step in bounds, 16-B aligned): branch-free 16-B loads that the compiler
+// can issue back to back.
+template <bool KMAJOR, int R>
+__device__ __forceinline__ void load_tile_full(const float* __restrict__ base, int64_t ld, int64_t row0, int64_t k0,
+                                               float4 (&reg)[R / 32]) {
+    const int t = threadIdx.x;
+    if (KMAJOR) {
+        const float* p = base + (row0 + (t >> 3)) * ld + k0 + 4 * (t & 7);
+#pragma unroll
+        for (int j = 0; j < R / 32; ++j) reg[j] = *reinterpret_cast<const float4*>(p + (int64_t)(32 * j) * ld);
+    } else {
+        constexpr int RV = R / 4;
+        constexpr int KSTEP = NTHREADS / RV;
+        const float* p = base + (k0 + t / RV) * ld + row0 + 4 * (t % RV);
+#pragma unroll
+        for (int j = 0; j < R / 32; ++j) reg[j] = *reinterpret_cast<const float4*>(p + (int64_t)(KSTEP * j) * ld);
+    }
+}
+
 template <bool KMAJOR, int R, bool VEC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_t ld, int64_t row0, int64_t rows,
                                           int64_t k0, int64_t kend, float4 (&reg)[R / 32]) {
@@ -164,9 +183,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
     float4 ra[BM / 32], rb[BN / 32];
+    const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N);  // workgroup-uniform
+    auto fetch = [&](int64_t k0) {
+        if (interior && k0 + BK <= kend) {
+            load_tile_full<AK, BM>(A, p.lda, m0, k0, ra);
+            load_tile_full<BKM, BN>(B, p.ldb, n0, k0, rb);
+        } else {
+            load_tile<AK, BM, VEC>(A, p.lda, m0, p.M, k0, kend, ra);
+            load_tile<BKM, BN, VEC>(B, p.ldb, n0, p.N, k0, kend, rb);
+        }
+    };
     if (nk > 0) {
-        load_tile<AK, BM, VEC>(A, p.lda, m0, p.M, kbeg, kend, ra);
-        load_tile<BKM, BN, VEC>(B, p.ldb, n0, p.N, kbeg, kend, rb);
+        fetch(kbeg);
         store_tile<AK, BM>(smem, ra);
         store_tile<BKM, BN>(smem + SA, rb);
     }
@@ -177,11 +205,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
         const float* sa = smem + cur * (SA + SB);
         const float* sb = sa + SA;
         const bool more = kt + 1 < nk;
-        if (more) {
-            const int64_t k0 = kbeg + (int64_t)(kt + 1) * BK;
-            load_tile<AK, BM, VEC>(A, p.lda, m0, p.M, k0, kend, ra);
-            load_tile<BKM, BN, VEC>(B, p.ldb, n0, p.N, k0, kend, rb);
-        }
+        if (more) fetch(kbeg + (int64_t)(kt + 1) * BK);
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
             float fa[WTM][4], fb[WTN][4];
@@ -218,6 +242,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
                 for (int e = 0; e < 16; ++e) {
                     const int64_t row = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (row < p.M && col < p.N) W[row * p.N + col] = acc[a][b][e];
+                }
+            }
+    } else if (m0 + BM <= p.M && n0 + BN <= p.N) {  // interior tile: unguarded stores
+        float* C = p.C + z1 * p.sc1 + z2 * p.sc2;
+#pragma unroll
+        for (int a = 0; a < WTM; ++a)
+#pragma unroll
+            for (int b = 0; b < WTN; ++b) {
+                const int64_t col = n0 + wn * (BN / 2) + b * 32 + i;
+                const float bv = p.bias ? p.bias[col] : 0.f;
+                float* cp = C + (m0 + wm * (BM / 2) + a * 32 + 4 * h) * p.ldc + col;
+                if (p.beta != 0.f) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float* q2 = cp + (int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc;
+                        *q2 = p.alpha * acc[a][b][e] + p.beta * *q2 + bv;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) cp[(int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc] = p.alpha * acc[a][b][e] + bv;
                 }
             }
     } else {

@@ -85,6 +85,7 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha
     if prof is not None:
         prof["calls"] += 1
         prof["flops"] += 2.0 * M * N * K * nb1 * nb2
+        prof["bytes"] += 4.0 * nb1 * nb2 * (M * K + K * N + M * N * (2 if beta != 0.0 else 1))  # algorithmic operand bytes
         if prof["calls"] % prof["every"] == 0:  # HIP events on the launch stream around this one launch
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -102,7 +103,7 @@ GEMM_PROFILE = None
 def gemm_profile_start(every=8):
     """Sample every `every`-th GEMM launch with a HIP-event pair (bench.py's live roofline measurement)."""
     global GEMM_PROFILE
-    GEMM_PROFILE = {"calls": 0, "flops": 0.0, "every": int(every), "samples": []}
+    GEMM_PROFILE = {"calls": 0, "flops": 0.0, "bytes": 0.0, "every": int(every), "samples": []}
 
 
 def gemm_profile_stop():
@@ -113,8 +114,8 @@ def gemm_profile_stop():
         return None
     fl = sum(s[0] for s in prof["samples"])
     ms = sum(s[1].elapsed_time(s[2]) for s in prof["samples"])
-    return {"calls": prof["calls"], "flops": prof["flops"], "sampled": len(prof["samples"]), "sampled_flops": fl,
-            "sampled_ms": ms}
+    return {"calls": prof["calls"], "flops": prof["flops"], "bytes": prof["bytes"], "sampled": len(prof["samples"]),
+            "sampled_flops": fl, "sampled_ms": ms}
 
 
 def linear(x, w, bias=None, out=None, alpha=1.0, beta=0.0):
