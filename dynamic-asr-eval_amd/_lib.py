@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdyneval_hip.so")
+LIB_PATH = os.environ.get("DYN_LIB_PATH") or os.path.join(_HERE, "libdyneval_hip.so")  # override: A/B builds only
 _lib = None
 
 
@@ -27,6 +27,7 @@ class GemmDesc(ctypes.Structure):
         ("nb1", ctypes.c_int64), ("nb2", ctypes.c_int64),
         ("split_k", ctypes.c_int32),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
+        ("tile_m", ctypes.c_int32), ("tile_n", ctypes.c_int32), ("tail_slices", ctypes.c_int32), ("reserved_", ctypes.c_int32),
     ]
 
 

@@ -23,8 +23,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 32;
+#ifndef DYN_GEMM_BK
+#define DYN_GEMM_BK 32
+#endif
+constexpr int BK = DYN_GEMM_BK;
 constexpr int LDK = BK + 4;
+constexpr int KV = BK / 4;            // float4 per staged row when K is contiguous
+constexpr int RP = 256 / KV;          // rows staged per pass of the 256 threads
 constexpr int NTHREADS = 256;
 
 struct KParams {
@@ -40,6 +45,10 @@ struct KParams {
     float* ws;        // split-K slabs [splits][batch][M][N]
     int64_t nbatch;
     int tiles_n;
+    int64_t tiles_per_batch;
+    int64_t full_items;  // work items (batch, tile, k-split) handled by one workgroup each; the rest is the TAIL
+    int tail_f;          // every tail item is cut into tail_f K-slices so the last partial round of workgroups still
+    float* tail_ws;      // fills the chip; slices go to tile-local slabs [tail item][slice][BM][BN] and are summed in order
 };
 
 // Stage one operand tile (R rows x BK) from HBM into registers.
@@ -47,30 +56,30 @@ struct KParams {
 // can issue back to back.
 template <bool KMAJOR, int R>
 __device__ __forceinline__ void load_tile_full(const float* __restrict__ base, int64_t ld, int64_t row0, int64_t k0,
-                                               float4 (&reg)[R / 32]) {
+                                               float4 (&reg)[(R * BK / 1024)]) {
     const int t = threadIdx.x;
     if (KMAJOR) {
-        const float* p = base + (row0 + (t >> 3)) * ld + k0 + 4 * (t & 7);
+        const float* p = base + (row0 + (t / KV)) * ld + k0 + 4 * (t % KV);
 #pragma unroll
-        for (int j = 0; j < R / 32; ++j) reg[j] = *reinterpret_cast<const float4*>(p + (int64_t)(32 * j) * ld);
+        for (int j = 0; j < (R * BK / 1024); ++j) reg[j] = *reinterpret_cast<const float4*>(p + (int64_t)(RP * j) * ld);
     } else {
         constexpr int RV = R / 4;
         constexpr int KSTEP = NTHREADS / RV;
         const float* p = base + (k0 + t / RV) * ld + row0 + 4 * (t % RV);
 #pragma unroll
-        for (int j = 0; j < R / 32; ++j) reg[j] = *reinterpret_cast<const float4*>(p + (int64_t)(KSTEP * j) * ld);
+        for (int j = 0; j < (R * BK / 1024); ++j) reg[j] = *reinterpret_cast<const float4*>(p + (int64_t)(KSTEP * j) * ld);
     }
 }
 
 template <bool KMAJOR, int R, bool VEC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_t ld, int64_t row0, int64_t rows,
-                                          int64_t k0, int64_t kend, float4 (&reg)[R / 32]) {
+                                          int64_t k0, int64_t kend, float4 (&reg)[(R * BK / 1024)]) {
     const int t = threadIdx.x;
     if (KMAJOR) {
-        const int c4 = t & 7;
+        const int c4 = t % KV;
 #pragma unroll
-        for (int j = 0; j < R / 32; ++j) {
-            const int r = (t >> 3) + 32 * j;
+        for (int j = 0; j < (R * BK / 1024); ++j) {
+            const int r = (t / KV) + RP * j;
             const int64_t gr = row0 + r, gk = k0 + 4 * c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gr < rows) {
@@ -91,7 +100,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_
         constexpr int KSTEP = NTHREADS / RV;
         const int r4 = t % RV;
 #pragma unroll
-        for (int j = 0; j < R / 32; ++j) {
+        for (int j = 0; j < (R * BK / 1024); ++j) {
             const int k = t / RV + KSTEP * j;
             const int64_t gk = k0 + k, gr = row0 + 4 * r4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -112,13 +121,13 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_
 }
 
 template <bool KMAJOR, int R>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&reg)[R / 32]) {
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&reg)[(R * BK / 1024)]) {
     const int t = threadIdx.x;
     if (KMAJOR) {
-        const int c4 = t & 7;
+        const int c4 = t % KV;
 #pragma unroll
-        for (int j = 0; j < R / 32; ++j) {
-            const int r = (t >> 3) + 32 * j;
+        for (int j = 0; j < (R * BK / 1024); ++j) {
+            const int r = (t / KV) + RP * j;
             *reinterpret_cast<float4*>(&s[r * LDK + 4 * c4]) = reg[j];
         }
     } else {
@@ -126,7 +135,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (
         constexpr int KSTEP = NTHREADS / RV;
         const int r4 = t % RV;
 #pragma unroll
-        for (int j = 0; j < R / 32; ++j) {
+        for (int j = 0; j < (R * BK / 1024); ++j) {
             const int k = t / RV + KSTEP * j;
             *reinterpret_cast<float4*>(&s[k * (R + 4) + 4 * r4]) = reg[j];
         }
@@ -153,22 +162,42 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
     constexpr int SA = BM * LDK, SB = BN * LDK;  // floats per stage (upper bound for both layouts)
     __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
 
-    // XCD-aware bijective remap of the tile index (blocks with equal blockIdx.x % 8 share an XCD/L2).
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    // Work item of this workgroup.  Full items: XCD-aware bijective remap (blocks with equal blockIdx.x % 8 share an
+    // XCD/L2, so each XCD walks a contiguous run of tiles).  Tail items come last in dispatch order and are K-sliced.
+    const int64_t bid = blockIdx.x;
+    const bool is_tail = bid >= p.full_items;
+    int64_t item;
+    int sub = 0;
+    if (!is_tail) {
+        const int64_t nwg = p.full_items;
+        const int64_t xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    } else {
+        const int64_t t = bid - p.full_items;
+        item = p.full_items + t / p.tail_f;
+        sub = (int)(t % p.tail_f);
+    }
+    const int ks = (int)(item % p.splits);
+    const int64_t t2 = item / p.splits;
+    const int tile = (int)(t2 % p.tiles_per_batch);
+    const int zb = (int)(t2 / p.tiles_per_batch);
     const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-
-    const int z = blockIdx.y;
-    const int zb = z / p.splits, ks = z % p.splits;
     const int64_t z1 = zb / p.nb2, z2 = zb % p.nb2;
     const float* A = p.A + z1 * p.sa1 + z2 * p.sa2;
     const float* B = p.B + z1 * p.sb1 + z2 * p.sb2;
 
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-    const int64_t kbeg = (int64_t)ks * p.kchunk;
-    const int64_t kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
-    const int nk = (int)((kend - kbeg + BK - 1) / BK);
+    int64_t kbeg = (int64_t)ks * p.kchunk;
+    int64_t kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
+    if (is_tail) {
+        const int64_t kt_all = (kend - kbeg + BK - 1) / BK;
+        const int64_t per = (kt_all + p.tail_f - 1) / p.tail_f;
+        const int64_t kb2 = kbeg + (int64_t)sub * per * BK;
+        const int64_t ke2 = kb2 + per * BK;
+        kend = ke2 < kend ? ke2 : kend;
+        kbeg = kb2;
+    }
+    const int nk = kend > kbeg ? (int)((kend - kbeg + BK - 1) / BK) : 0;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
@@ -182,7 +211,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    float4 ra[BM / 32], rb[BN / 32];
+    float4 ra[BM * BK / 1024], rb[BN * BK / 1024];
     const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N);  // workgroup-uniform
     auto fetch = [&](int64_t k0) {
         if (interior && k0 + BK <= kend) {
@@ -231,7 +260,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
     }
 
     // Epilogue. C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    if (p.splits > 1) {
+    if (is_tail) {
+        float* W = p.tail_ws + ((item - p.full_items) * p.tail_f + sub) * (int64_t)(BM * BN);
+#pragma unroll
+        for (int a = 0; a < WTM; ++a)
+#pragma unroll
+            for (int b = 0; b < WTN; ++b) {
+                float* wp = W + (wm * (BM / 2) + a * 32 + 4 * h) * BN + wn * (BN / 2) + b * 32 + i;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) wp[((e & 3) + 8 * (e >> 2)) * BN] = acc[a][b][e];
+            }
+    } else if (p.splits > 1) {
         float* W = p.ws + ((int64_t)ks * p.nbatch + zb) * p.M * p.N;
 #pragma unroll
         for (int a = 0; a < WTM; ++a)
@@ -303,43 +342,131 @@ __global__ void splitk_reduce_kernel(const KParams p) {
     }
 }
 
+// C tile = alpha * sum_slices slab + beta * C + bias for every tail item (slices added in order: deterministic).
+__global__ __launch_bounds__(256) void tail_reduce_kernel(const KParams p, int BM, int BN, int64_t tail_items) {
+    const int per_tile = BM * BN / 4;  // float4 per tile
+    const int64_t total = tail_items * per_tile;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ti = idx / per_tile;
+        const int e4 = (int)(idx % per_tile);
+        const int r = (e4 * 4) / BN, c = (e4 * 4) % BN;
+        const float4* W = reinterpret_cast<const float4*>(p.tail_ws + (ti * p.tail_f) * (int64_t)(BM * BN)) + e4;
+        float4 s4 = W[0];
+        for (int k = 1; k < p.tail_f; ++k) {
+            const float4 v = W[(int64_t)k * per_tile];
+            s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+        }
+        const int64_t item = p.full_items + ti;  // splits == 1 in tail mode
+        const int tile = (int)(item % p.tiles_per_batch);
+        const int zb = (int)(item / p.tiles_per_batch);
+        const int64_t row = (int64_t)(tile / p.tiles_n) * BM + r, col0 = (int64_t)(tile % p.tiles_n) * BN + c;
+        if (row >= p.M) continue;
+        const int64_t z1 = zb / p.nb2, z2 = zb % p.nb2;
+        float* C = p.C + z1 * p.sc1 + z2 * p.sc2 + row * p.ldc;
+        const float v[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t col = col0 + j;
+            if (col < p.N) {
+                float o = p.alpha * v[j];
+                if (p.beta != 0.f) o += p.beta * C[col];
+                if (p.bias) o += p.bias[col];
+                C[col] = o;
+            }
+        }
+    }
+}
+
 struct Plan {
     int bm, bn, splits;
     int64_t kchunk;
-    int64_t ws_bytes;
+    int64_t ws_bytes;       // global split-K slabs
+    int64_t full_items;
+    int64_t tail_items;
+    int tail_f;
+    int64_t tail_ws_bytes;
 };
 
-Plan make_plan(const dyn_gemm_desc* d) {
-    Plan pl;
+// Tile / split selection by a small cost model (all shapes of this path are known up front: M in {2048, 4096, 8192,...},
+// N, K in {128 ... 4096}).  A "round" is one workgroup per slot (slots = resident workgroups per CU x 256 CUs); a partial
+// last round is the classic wave-quantisation loss, so when no global split-K is used its items are K-sliced tail_f ways
+// (tail_f = slots / remainder) and run as one short, full round.
+double tile_eff(int bm, int bn) { return (bm == 128 && bn == 128) ? 0.80 : (bm == 64 && bn == 64) ? 0.62 : 0.72; }
+int tile_occ(int bm, int bn) { return (bm == 64 && bn == 64) ? 4 : 2; }
+
+// One configuration: tile (bm, bn), global split-K s, tail slicing f_req (-1 = slots / remainder, 1 = off, n = forced).
+bool eval_config(const dyn_gemm_desc* d, int bm, int bn, int s, int f_req, Plan* out, double* cost) {
     const int64_t batch = d->nb1 * d->nb2;
-    auto blocks = [&](int bm, int bn) { return dyn::cdiv(d->M, bm) * dyn::cdiv(d->N, bn) * batch; };
-    // Largest tile that still gives every CU about two workgroups; otherwise the smallest tile.
-    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    pl.bm = 64; pl.bn = 64;
-    for (int c = 0; c < 4; ++c) {
-        if (blocks(cand[c][0], cand[c][1]) >= 448) { pl.bm = cand[c][0]; pl.bn = cand[c][1]; break; }
+    const int64_t ktiles = dyn::cdiv(d->K > 0 ? d->K : 1, BK);
+    if (s < 1) s = 1;
+    if (s > ktiles) s = (int)ktiles;
+    const int64_t tiles = dyn::cdiv(d->M, bm) * dyn::cdiv(d->N, bn);
+    const int64_t slots = (int64_t)tile_occ(bm, bn) * 256;
+    const int64_t kchunk = dyn::cdiv(ktiles, s) * BK;
+    const int s_eff = (int)dyn::cdiv(d->K > 0 ? d->K : 1, kchunk);
+    const int64_t items = tiles * batch * s_eff;
+    const int64_t rounds = items / slots, rem = items % slots;
+    int f = 1;
+    if (s_eff == 1 && rem > 0 && f_req != 1) {
+        f = f_req > 1 ? f_req : (int)(slots / rem);
+        const int64_t maxf = ktiles / 2 > 0 ? ktiles / 2 : 1;  // keep >= 2 K steps per slice
+        if (f > maxf) f = (int)maxf;
+        if (f > 16) f = 16;
+        if (f < 1) f = 1;
     }
-    if (d->M <= 64 && pl.bm == 128) pl.bm = 64;
-    if (d->N <= 64 && pl.bn == 128) pl.bn = 64;
-    int splits = d->split_k;
-    const int64_t nb = blocks(pl.bm, pl.bn);
-    if (splits == 0) {  // auto: only when the grid cannot fill the chip and K is deep
-        splits = 1;
-        if (nb < 256 && d->K >= 1024) {
-            int64_t want = dyn::cdiv(512, nb), maxs = d->K / 256;
-            splits = (int)(want < maxs ? want : maxs);
-            if (splits < 1) splits = 1;
-            if (splits > 32) splits = 32;
+    // seconds: one round = occ tiles per CU, each 2*bm*bn*kchunk flops at eff * 614 GFLOP/s per CU
+    const double round_t = tile_occ(bm, bn) * 2.0 * bm * bn * (double)kchunk / (614e9 * tile_eff(bm, bn));
+    double t = rounds * round_t + (rem > 0 ? round_t / f + 1.0e-6 : 0.0);
+    if (s_eff > 1) t += 3e-6 + (double)s_eff * d->M * d->N * batch * 4.0 * 2.0 / 3.0e12;
+    if (f > 1) t += 2e-6 + (double)f * rem * bm * bn * 4.0 * 2.0 / 3.0e12;
+    *cost = t;
+    out->bm = bm; out->bn = bn; out->splits = s_eff; out->kchunk = kchunk;
+    out->ws_bytes = s_eff > 1 ? (int64_t)s_eff * batch * d->M * d->N * (int64_t)sizeof(float) : 0;
+    out->tail_f = f;
+    out->tail_items = f > 1 ? rem : 0;
+    out->full_items = items - out->tail_items;
+    out->tail_ws_bytes = f > 1 ? rem * f * (int64_t)bm * bn * (int64_t)sizeof(float) : 0;
+    return true;
+}
+
+struct Tuned { int ta, tb; int64_t M, N, K, batch; int bm, bn, split, tail; };
+#include "gemm_tuned.inc"   // generated by scripts/tune_gemm.py on an MI355X: static const Tuned kTuned[]; kNumTuned
+
+Plan make_plan(const dyn_gemm_desc* d) {
+    Plan best;
+    double cost;
+    if (d->tile_m > 0 && d->tile_n > 0) {  // caller-forced configuration (autotuner, tests)
+        eval_config(d, d->tile_m >= 128 ? 128 : 64, d->tile_n >= 128 ? 128 : 64, d->split_k > 0 ? d->split_k : 1,
+                    d->tail_slices > 0 ? d->tail_slices : 1, &best, &cost);
+        return best;
+    }
+    const int64_t batch = d->nb1 * d->nb2;
+    if (d->split_k == 0) {
+        for (int i = 0; i < kNumTuned; ++i) {
+            const Tuned& t = kTuned[i];
+            if (t.ta == (d->trans_a != 0) && t.tb == (d->trans_b != 0) && t.M == d->M && t.N == d->N && t.K == d->K && t.batch == batch) {
+                eval_config(d, t.bm, t.bn, t.split, t.tail, &best, &cost);
+                return best;
+            }
         }
     }
-    if (splits < 1) splits = 1;
-    int64_t ktiles = dyn::cdiv(d->K, BK);
-    if (splits > ktiles) splits = (int)(ktiles > 0 ? ktiles : 1);
-    pl.kchunk = dyn::cdiv(ktiles, splits) * BK;
-    splits = (int)dyn::cdiv(d->K > 0 ? d->K : 1, pl.kchunk);
-    pl.splits = splits;
-    pl.ws_bytes = splits > 1 ? (int64_t)splits * batch * d->M * d->N * (int64_t)sizeof(float) : 0;
-    return pl;
+    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    int split_opts[9] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+    int n_opts = 9;
+    if (d->split_k > 0) { split_opts[0] = d->split_k; n_opts = 1; }   // caller forced a split factor
+    double best_cost = 1e300;
+    for (int c = 0; c < 4; ++c) {
+        const int bm = cand[c][0], bn = cand[c][1];
+        if ((d->M <= 64 && bm == 128) || (d->N <= 64 && bn == 128)) continue;
+        for (int so = 0; so < n_opts; ++so) {
+            const int s = split_opts[so];
+            if (d->split_k == 0 && s > 1 && (d->K / s < 256)) continue;
+            Plan pl;
+            eval_config(d, bm, bn, s, d->split_k == 0 ? -1 : 1, &pl, &cost);
+            if (cost < best_cost) { best_cost = cost; best = pl; }
+        }
+    }
+    return best;
 }
 
 template <bool TA, bool TB, int BM, int BN>
@@ -360,7 +487,8 @@ void launch_tile(const KParams& kp, const Plan& pl, bool vec, dim3 grid, hipStre
 
 extern "C" int64_t dyn_gemm_f32_workspace_bytes(const dyn_gemm_desc* d) {
     if (!d || d->M <= 0 || d->N <= 0 || d->nb1 <= 0 || d->nb2 <= 0) return 0;
-    return make_plan(d).ws_bytes;
+    const Plan pl = make_plan(d);
+    return pl.ws_bytes > pl.tail_ws_bytes ? pl.ws_bytes : pl.tail_ws_bytes;
 }
 
 extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
@@ -373,12 +501,15 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
     DYN_REQUIRE(d->lda >= (d->trans_a ? d->M : d->K) && d->ldb >= (d->trans_b ? d->K : d->N) && d->ldc >= d->N,
                 DYN_E_ARG, "dyn_gemm_f32: leading dimension smaller than the row length");
     Plan pl = make_plan(d);
-    if (pl.splits > 1 && (d->workspace == nullptr || d->workspace_bytes < pl.ws_bytes)) {
+    const int64_t need = pl.ws_bytes > pl.tail_ws_bytes ? pl.ws_bytes : pl.tail_ws_bytes;
+    if (need > 0 && (d->workspace == nullptr || d->workspace_bytes < need)) {
         DYN_REQUIRE(d->split_k == 0, DYN_E_WORKSPACE, "dyn_gemm_f32: split_k=%d needs %lld workspace bytes, got %lld",
-                    d->split_k, (long long)pl.ws_bytes, (long long)d->workspace_bytes);
-        pl.splits = 1;  // auto split silently degrades to a single pass
+                    d->split_k, (long long)need, (long long)d->workspace_bytes);
+        // no workspace: degrade to a single pass without K slicing (same result up to summation order)
+        pl.splits = 1;
         pl.kchunk = dyn::cdiv(d->K > 0 ? d->K : 1, BK) * BK;
-        pl.ws_bytes = 0;
+        pl.ws_bytes = 0; pl.tail_f = 1; pl.tail_items = 0; pl.tail_ws_bytes = 0;
+        pl.full_items = dyn::cdiv(d->M, pl.bm) * dyn::cdiv(d->N, pl.bn) * d->nb1 * d->nb2;
     }
     const int64_t batch = d->nb1 * d->nb2;
     KParams kp;
@@ -391,13 +522,17 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
     kp.ws = (float*)d->workspace; kp.nbatch = batch;
     const int64_t tiles_m = dyn::cdiv(d->M, pl.bm), tiles_n = dyn::cdiv(d->N, pl.bn);
     kp.tiles_n = (int)tiles_n;
-    DYN_REQUIRE(tiles_m * tiles_n < (1ll << 31) && batch * pl.splits < 65536, DYN_E_ARG,
-                "dyn_gemm_f32: grid too large (tiles=%lld, z=%lld)", (long long)(tiles_m * tiles_n),
-                (long long)(batch * pl.splits));
+    kp.tiles_per_batch = tiles_m * tiles_n;
+    kp.full_items = pl.full_items;
+    kp.tail_f = pl.tail_f;
+    kp.tail_ws = (float*)d->workspace;
+    const int64_t nblocks = pl.full_items + pl.tail_items * pl.tail_f;
+    DYN_REQUIRE(nblocks < (1ll << 31) && tiles_m * tiles_n < (1ll << 31), DYN_E_ARG, "dyn_gemm_f32: grid too large (%lld workgroups)",
+                (long long)nblocks);
     auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
     const bool vec = al16(d->A) && al16(d->B) && (d->lda % 4 == 0) && (d->ldb % 4 == 0) && (d->sa1 % 4 == 0) &&
                      (d->sa2 % 4 == 0) && (d->sb1 % 4 == 0) && (d->sb2 % 4 == 0);
-    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)(batch * pl.splits));
+    dim3 grid((unsigned)nblocks);
     hipStream_t st = (hipStream_t)stream;
     if (!d->trans_a && !d->trans_b) launch_tile<false, false>(kp, pl, vec, grid, st);
     else if (!d->trans_a && d->trans_b) launch_tile<false, true>(kp, pl, vec, grid, st);
@@ -411,6 +546,11 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
         if (nblk > 2048) nblk = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, kp);
         rc = dyn::check_launch("dyn_gemm_f32(splitk_reduce)");
+    } else if (pl.tail_items > 0) {
+        int64_t nblk = dyn::cdiv(pl.tail_items * pl.bm * pl.bn / 4, 256);
+        if (nblk > 4096) nblk = 4096;
+        hipLaunchKernelGGL(tail_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, kp, pl.bm, pl.bn, pl.tail_items);
+        rc = dyn::check_launch("dyn_gemm_f32(tail_reduce)");
     }
     return rc;
 }

@@ -66,10 +66,13 @@ def workspace(device=None):
 
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
-         nb1=1, nb2=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, split_k=0):
-    """Raw strided batched GEMM (see dyn_gemm_desc). Offsets are in elements from each tensor's data_ptr."""
+         nb1=1, nb2=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, split_k=0, force=None):
+    """Raw strided batched GEMM (see dyn_gemm_desc). Offsets are in elements from each tensor's data_ptr.
+    `force=(tile_m, tile_n, tail_slices)` pins the kernel configuration (autotuner / tests)."""
     _chk(a, "gemm.A"); _chk(b, "gemm.B"); _chk(c, "gemm.C")
     d = GemmDesc()
+    if force is not None:
+        d.tile_m, d.tile_n, d.tail_slices = force
     d.trans_a, d.trans_b = int(trans_a), int(trans_b)
     d.M, d.N, d.K = M, N, K
     d.alpha, d.beta = alpha, beta

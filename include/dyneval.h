@@ -51,8 +51,12 @@ typedef struct {
     float* C;       int64_t ldc, sc1, sc2;
     const float* bias;      /* [N] or NULL; added once (after alpha/beta) */
     int64_t nb1, nb2;       /* batch = nb1 * nb2 (>= 1 each) */
-    int32_t split_k;        /* 0/1 = none */
+    int32_t split_k;        /* 0 = let the planner choose, n >= 1 = force n K-slices over the whole problem */
     void* workspace; int64_t workspace_bytes;
+    /* optional forced configuration (0 = planner: tuned table for known shapes, cost model otherwise); used by
+     * scripts/tune_gemm.py to time candidates: tile 64|128 x 64|128, tail_slices = K-slices of the last partial
+     * round of workgroups (1 = off) */
+    int32_t tile_m, tile_n, tail_slices, reserved_;
 } dyn_gemm_desc;
 
 int64_t dyn_gemm_f32_workspace_bytes(const dyn_gemm_desc* d);
