@@ -370,6 +370,12 @@ def dynamic_eval_ctc_loss(
 dynamic_eval = dynamic_eval_ctc_loss
 
 
+def AWMC(*a, **kw):
+    """Reference lcasr/lib.py:206-376 — implemented in awmc.py (same signature)."""
+    from .awmc import AWMC as _impl
+    return _impl(*a, **kw)
+
+
 # ------------------------------------------------------------------------------------------------ shared CLI surface
 def apply_args(parser, argv=None):
     """Reference lcasr/lib.py:1756-1787 (same flags, same free-form `-kwargs k=v` evaluated into args.__dict__)."""

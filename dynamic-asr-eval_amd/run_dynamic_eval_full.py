@@ -68,9 +68,9 @@ def main(args):
     model, tokenizer = load_model_and_tokenizer(args, device)
     decoder = GreedyCTCDecoder(tokenizer=tokenizer, blank_id=model.decoder.num_classes - 1, device=device)
     data = datasets_functions[args.dataset](args.split)
-    if args.awmc or args.consistency:
-        raise NotImplementedError('AWMC / consistency variants are not part of this round (SURVEY.md §8f)')
-    eval_fn = dynamic_eval
+    if args.consistency:
+        raise NotImplementedError('dynamic_eval_consistency_ctc_loss is out of scope (SURVEY.md §2 row 3)')
+    eval_fn = lib.AWMC if args.awmc else dynamic_eval                   # reference run_dynamic_eval_full.py:67-72
     mine = ddist.shard_longest_first([d.get('frames', 1) for d in data], world)[rank]
 
     avg_wers = []

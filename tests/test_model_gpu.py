@@ -126,3 +126,53 @@ def test_dynamic_eval_short_recording_and_epochs0(cuda):
     assert out.shape == out_ref.shape
     assert np.abs(out - out_ref).max() < 2e-4
     assert np.array_equal(out.argmax(-1), out_ref.argmax(-1))
+
+
+def test_awmc_parity(cuda):
+    """AWMC (reference lcasr/lib.py:206-376) on the HIP path vs the CPU oracle: 2 epochs so the leader EMA moves."""
+    from oracle.awmc_ref import awmc_ref
+    from oracle import dynamic_eval_ref as R
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    ref, hip = _pair(cuda, SMALL, vocab=128, seed=9, blank_bias=1.5)
+    tok = SyntheticTokenizer(128)
+    spec = torch.randn(1, 80, 1100, generator=torch.Generator().manual_seed(21))
+    seq_len, overlap = 512, 256
+    _, keys = R.prepare_chunks(spec, seq_len, overlap)
+    masks = _masks_for(keys, 80, None, seed=4)
+    before = hip.flat_params.clone()
+    out_ref, p_ref = awmc_ref(ref, spec, seq_len, overlap, tok, MADGRAD_REF, {'lr': 1e-4}, {}, epochs=2, ema_decay=0.999,
+                              fixed_masks=masks, return_params=True)
+    args = _args(optim_lr=1e-4, epochs=2, ema_decay=0.999, spec_augment_fixed_masks=masks, quiet=True)
+    out, p = lib.AWMC(args, hip, spec, seq_len, overlap, tok, use_tqdm=False, return_params=True)
+    assert torch.equal(hip.flat_params, before)
+    assert out.shape == out_ref.shape and np.abs(out - out_ref).max() < 1e-3
+    assert np.array_equal(out.argmax(-1), out_ref.argmax(-1))
+    for a, b in zip(p, p_ref):
+        assert (a - b).abs().max().item() < 5e-5
+
+
+def test_adapt_on_concat_only_matches_loop_a(cuda):
+    """run_half_concat_eval.adapt_on_concat_only (reference :64-160) = Loop A of dynamic eval on the concatenation."""
+    from oracle import dynamic_eval_ref as R
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd.run_half_concat_eval import adapt_on_concat_only, concatenate_specs
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    ref, hip = _pair(cuda, SMALL, vocab=128, seed=13, blank_bias=1.5)
+    tok = SyntheticTokenizer(128)
+    g = torch.Generator().manual_seed(31)
+    specs = [torch.randn(1, 80, n, generator=g) for n in (700, 500, 300)]
+    concat = concatenate_specs(specs)
+    _, keys = R.prepare_chunks(concat, 512, 256)
+    masks = _masks_for(keys, 80, None, seed=6)
+    _, p_ref = R.dynamic_eval_ref(ref, concat, 512, 256, tok, MADGRAD_REF, {'lr': 1e-4}, {}, epochs=1, fixed_masks=masks,
+                                  return_params=True)
+    args = _args(optim_lr=1e-4, epochs=1, shuffle=False, seq_len=512, awmc=False, spec_augment_fixed_masks=masks, quiet=True)
+    before = hip.flat_params.clone()
+    p = adapt_on_concat_only(args, hip, concat, tok, adapt_overlap=256)
+    assert torch.equal(hip.flat_params, before)
+    for a, b in zip(p, p_ref):
+        assert (a - b).abs().max().item() < 5e-5
+    with pytest.raises(ValueError):
+        concatenate_specs([])
