@@ -49,3 +49,70 @@ class SpecAugment:
             ops.specaug_timemask(window, torch.tensor(t0, dtype=torch.int32, device=dev),
                                  torch.tensor(tw, dtype=torch.int32, device=dev), fill_value)
         return window
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Optional augmentations of Loop A (reference lcasr/lib.py:542-544).  Random draws use the caller's torch CPU RNG in the
+# reference's order; the data movement / arithmetic runs on the device window ([F, T], contiguous, modified in place).
+def _moments(window):
+    from ._lib import check, load
+    out = torch.empty(3, device=window.device, dtype=torch.float32)
+    ws = ops.workspace(window.device)
+    check(load().dyn_moments(window.data_ptr(), window.numel(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                             torch.cuda.current_stream().cuda_stream), "dyn_moments")
+    s, mean, std = out.cpu().tolist()
+    return s, mean, std
+
+
+def frame_shuffle(window, time_dimension=False, freq_dimension=False):
+    """reference lib.py:81-84"""
+    from ._lib import check, load
+    F, T = window.shape
+    for along_time, n, on in ((1, T, time_dimension), (0, F, freq_dimension)):
+        if not on:
+            continue
+        perm = torch.randperm(n).to(torch.int32).to(window.device)
+        src = window.clone()
+        check(load().dyn_gather_frames(src.data_ptr(), perm.data_ptr(), window.data_ptr(), F, T, along_time,
+                                       torch.cuda.current_stream().cuda_stream), "dyn_gather_frames")
+    return window
+
+
+def add_random_noise(window, noise_factor):
+    """reference lib.py:379-382: spec + N(0, spec.std()) * noise_factor (noise drawn on the host like the reference)."""
+    if noise_factor == 0:
+        return window
+    _, _, std = _moments(window)
+    noise = torch.normal(0, std=std, size=tuple(window.shape)).to(window.device)
+    ops.axpby(noise, window, a=float(noise_factor), b=1.0)
+    return window
+
+
+def cutout(window, seq_len, cutout_val='mean', num_rectangles=5, max_width=100, max_height=10):
+    """reference lib.py:384-417 (same draw order: widths, heights, start x, start y)."""
+    from ._lib import check, load
+    if num_rectangles == 0:
+        return window
+    F, T = window.shape
+    num_rectangles = int(num_rectangles * (T / seq_len))
+    if num_rectangles <= 0:
+        return window
+    widths = torch.randint(1, max_width, (num_rectangles,))
+    heights = torch.randint(1, max_height, (num_rectangles,))
+    sx = torch.randint(0, T, (num_rectangles,))
+    ex = (sx + widths).clamp(max=T)
+    sy = torch.randint(0, F, (num_rectangles,))
+    ey = (sy + heights).clamp(max=F)
+    rects = torch.stack([sy, ey, sx, ex], 1).to(torch.int32).contiguous().to(window.device)
+    means = torch.empty(num_rectangles, device=window.device, dtype=torch.float32)
+    if cutout_val == 'mean':
+        mode, value = 1, 0.0
+    elif cutout_val == 'mean_recording':
+        mode, value = 2, _moments(window)[1]
+    elif cutout_val == 'zero':
+        mode, value = 0, 0.0
+    else:
+        raise ValueError(f"unknown cutout value {cutout_val!r}")
+    check(load().dyn_cutout(window.data_ptr(), F, T, rects.data_ptr(), num_rectangles, mode, value, means.data_ptr(),
+                            torch.cuda.current_stream().cuda_stream), "dyn_cutout")
+    return window

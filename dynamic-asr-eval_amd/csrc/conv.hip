@@ -123,6 +123,35 @@ __global__ __launch_bounds__(256) void conv2d_first_fwd_kernel(const float* __re
     }
 }
 
+// dgrad of the first conv (only the entropy-gradient input perturbation needs it, reference lcasr/lib.py:86-99):
+//   dx[b,t,f] = sum_c sum_{(to,dt),(fo,df): 2to+dt-1 = t, 2fo+df-1 = f} w[c,dt,df] * dz[b,to,fo,c]
+// one wave per output element: lanes stride the channels, wavefront reduction at the end.
+__global__ __launch_bounds__(256) void conv2d_first_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                                  float* __restrict__ dx, int64_t B, int64_t T, int F,
+                                                                  int64_t To, int Fo, int C) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t total = B * T * F;
+    for (int64_t e = (int64_t)blockIdx.x * 4 + wv; e < total; e += (int64_t)gridDim.x * 4) {
+        const int f = (int)(e % F);
+        const int64_t t = (e / F) % T, b = e / ((int64_t)F * T);
+        float acc = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int64_t tt = t + 1 - dt;
+            if (tt < 0 || (tt & 1) || (tt >> 1) >= To) continue;
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                const int ff = f + 1 - df;
+                if (ff < 0 || (ff & 1) || (ff >> 1) >= Fo) continue;
+                const float* g = dz + ((b * To + (tt >> 1)) * Fo + (ff >> 1)) * C;
+                for (int c = lane; c < C; c += 64) acc += w[c * 9 + dt * 3 + df] * g[c];
+            }
+        }
+        acc = dyn::wave_sum(acc);
+        if (lane == 0) dx[e] = acc;
+    }
+}
+
 // wgrad of the first conv: partial[(b,to-chunk), c, 9] and bias partial.
 __global__ __launch_bounds__(256) void conv2d_first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                   float* __restrict__ partial_w, float* __restrict__ partial_b,
@@ -342,6 +371,18 @@ extern "C" int dyn_conv2d_first_fwd(const float* x, const float* w, const float*
     dim3 grid((unsigned)To, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
     hipLaunchKernelGGL(conv2d_first_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, z, T, (int)F, To, (int)Fo, (int)C);
     return dyn::check_launch("dyn_conv2d_first_fwd");
+}
+
+extern "C" int dyn_conv2d_first_dgrad(const float* dz, const float* w, float* dx, int64_t B, int64_t T, int64_t F, int64_t C,
+                                      void* stream) {
+    DYN_REQUIRE(dz && w && dx && B >= 0 && T > 0 && F > 0 && C > 0, DYN_E_ARG, "dyn_conv2d_first_dgrad: bad arguments");
+    if (B == 0) return DYN_OK;
+    const int64_t To = (T - 1) / 2 + 1, Fo = (F - 1) / 2 + 1;
+    int64_t g = dyn::cdiv(B * T * F, 4);
+    if (g > 65536) g = 65536;
+    hipLaunchKernelGGL(conv2d_first_dgrad_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, dz, w, dx, B, T, (int)F, To,
+                       (int)Fo, (int)C);
+    return dyn::check_launch("dyn_conv2d_first_dgrad");
 }
 
 extern "C" int64_t dyn_conv2d_wgrad_workspace_bytes(int64_t B, int64_t To, int64_t C) {

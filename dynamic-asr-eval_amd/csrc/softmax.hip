@@ -81,6 +81,36 @@ __global__ __launch_bounds__(TPB) void softmax_bwd_kernel(const float* __restric
     }
 }
 
+// Gradient of the MEAN categorical entropy w.r.t. log-probabilities y (rows already normalised):
+//   H_row = -sum_c p_c y_c,  p = exp(y);   dH_row/dy_c = -p_c (y_c + H_row)   (the simplex projection included);
+//   grad = scale * dH_row/dy  with scale = 1 / rows for `entropy.mean()`  (reference lcasr/lib.py:94-96).
+template <int ITEMS>
+__global__ __launch_bounds__(TPB) void entropy_grad_kernel(const float* __restrict__ y, float* __restrict__ g,
+                                                            float* __restrict__ ent, int64_t rows, int L, int64_t ld,
+                                                            float scale) {
+    __shared__ float red[8];
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* yr = y + row * ld;
+        float yv[ITEMS], pv[ITEMS];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int c = threadIdx.x + j * TPB;
+            yv[j] = c < L ? yr[c] : 0.f;
+            pv[j] = c < L ? expf(yv[j]) : 0.f;
+            s -= pv[j] * yv[j];
+        }
+        const float H = dyn::block_sum(s, red);
+        float* gr = g + row * ld;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int c = threadIdx.x + j * TPB;
+            if (c < L) gr[c] = -pv[j] * (yv[j] + H) * scale;
+        }
+        if (ent && threadIdx.x == 0) ent[row] = H;
+    }
+}
+
 template <bool LOG>
 int launch_fwd(const float* x, float* y, int64_t rows, int64_t L, int64_t ldx, int64_t ldy, hipStream_t st) {
     int64_t g = rows < 65535 * 4 ? rows : 65535 * 4;
@@ -134,6 +164,26 @@ extern "C" int dyn_log_softmax_fwd(const float* x, float* y, int64_t rows, int64
     if (rows == 0) return DYN_OK;
     return launch_fwd<true>(x, y, rows, L, ldx, ldy, (hipStream_t)stream);
 }
+extern "C" int dyn_entropy_grad(const float* log_probs, float* grad, float* entropy_per_row, int64_t rows, int64_t L, int64_t ld,
+                                float scale, void* stream) {
+    DYN_REQUIRE(log_probs && grad && rows >= 0 && L > 0 && ld >= L, DYN_E_ARG, "dyn_entropy_grad: bad arguments");
+    if (rows == 0) return DYN_OK;
+    int64_t gq = rows < 65535 * 4 ? rows : 65535 * 4;
+    dim3 grid((unsigned)gq), blk(TPB);
+    hipStream_t st = (hipStream_t)stream;
+    const int items = (int)dyn::cdiv(L, TPB);
+#define GO(I) hipLaunchKernelGGL((entropy_grad_kernel<I>), grid, blk, 0, st, log_probs, grad, entropy_per_row, rows, (int)L, ld, scale)
+    if (items <= 1) GO(1);
+    else if (items <= 2) GO(2);
+    else if (items <= 4) GO(4);
+    else if (items <= 8) GO(8);
+    else if (items <= 16) GO(16);
+    else if (items <= 32) GO(32);
+    else { dyn::set_error("entropy_grad: row length %lld > 8192 unsupported", (long long)L); return DYN_E_UNSUPPORTED; }
+#undef GO
+    return dyn::check_launch("dyn_entropy_grad");
+}
+
 extern "C" int dyn_log_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int64_t L, int64_t ld,
                                    void* stream) {
     DYN_REQUIRE(y && dy && dx && rows >= 0 && L > 0 && ld >= L, DYN_E_ARG, "dyn_log_softmax_bwd: bad arguments");

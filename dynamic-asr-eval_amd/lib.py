@@ -21,6 +21,7 @@ import time
 import torch
 
 from . import ops
+from . import augment as _aug
 from .augment import SpecAugment
 from .decoding import GreedyCTCDecoder
 from .optim import MADGRAD, Adam  # noqa: F401  (re-exported: `optim=lib.MADGRAD`)
@@ -146,6 +147,21 @@ def _unsupported(name):
                               "yet; refusing to silently run without it")
 
 
+def entropy_augmentation(spec, model, **kwargs):
+    """Reference lcasr/lib.py:86-99: spec += 0.001 * d(mean entropy of the posteriors)/d(spec), in place on the device
+    window(s) `spec` [B, F, T].  Forward, entropy gradient (dyn_entropy_grad), backward to the input with every
+    weight-gradient product skipped."""
+    if not kwargs.get('enabled', False):
+        return spec
+    with torch.enable_grad():
+        lp = model(audio_signal=spec)['final_posteriors']
+    g, _ = ops.entropy_grad(lp, 1.0 / (lp.shape[0] * lp.shape[1]))        # entropy.mean() over B * N rows
+    dx = model.backward(g, input_grad=True, param_grads=False)
+    for b in range(spec.shape[0]):
+        ops.axpby(dx[b], spec[b], a=0.001, b=1.0)
+    return spec
+
+
 def dynamic_eval_ctc_loss(
         args,
         model,
@@ -182,14 +198,8 @@ def dynamic_eval_ctc_loss(
     verbose = bool(args.__dict__.get('verbose', False)) and not args.__dict__.get('quiet', False)
     if verbose:
         print(spec_augment_config, lr_args, frame_shuffle_args, cutout_args)
-    if random_noise:
-        _unsupported("random_noise")
-    if frame_shuffle_args['time_dimension'] or frame_shuffle_args['freq_dimension']:
-        _unsupported("frame_shuffle")
-    if cutout_args['num_rectangles']:
-        _unsupported("cutout")
-    if entropy_args.get('enabled', False):
-        _unsupported("entropy_augmentation")
+    if entropy_args.get('enabled', False) and not _is_native(model):
+        _unsupported("entropy_augmentation with a foreign torch model")
     num_negatives = 1
     native = _is_native(model)
 
@@ -280,6 +290,11 @@ def dynamic_eval_ctc_loss(
                 if masks[0][0] or masks[1][0]:
                     fill = _window_fill_value(audio_chunk[b], augmentation.zero_masking)
                     augmentation.apply(audio_chunk[b], masks, fill)
+                _aug.frame_shuffle(audio_chunk[b], **frame_shuffle_args)                 # reference lib.py:542
+                _aug.add_random_noise(audio_chunk[b], noise_factor=random_noise)         # lib.py:543
+                _aug.cutout(audio_chunk[b], **cutout_args)                               # lib.py:544
+            if entropy_args.get('enabled', False):
+                entropy_augmentation(audio_chunk[:num_negatives], model, **entropy_args)  # lib.py:545
 
             with torch.enable_grad():
                 out = model(audio_signal=audio_chunk)

@@ -120,6 +120,7 @@ class SCConformerXL:
         self.decoder = _Group(self, "decoder.", num_classes=self.num_classes)
         self._rot = {}
         self._ctx = None
+        self._skip_wgrad = False
         self.training = False
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -185,7 +186,7 @@ class SCConformerXL:
 
     def _lin_bwd(self, dy, x, wname, bname=None, need_dx=True, alpha=1.0):
         """Accumulates dW (and db) for y = x @ W^T + b and returns alpha * dy @ W (or None)."""
-        if self.trainable(wname):
+        if self.trainable(wname) and not self._skip_wgrad:
             ops.linear_wgrad(dy, x, self.G[wname], alpha=alpha, beta=1.0)
             if bname is not None:
                 ops.colsum(dy, self.G[bname], beta=1.0)
@@ -311,12 +312,21 @@ class SCConformerXL:
         return out
 
     # ------------------------------------------------------------------ backward
-    def backward(self, grad_posteriors, n_active=None):
+    def backward(self, grad_posteriors, n_active=None, input_grad=False, param_grads=True):
         """Gradient of a scalar loss w.r.t. every parameter, given dL/d(final_posteriors) [B, T', V+1].
         Accumulates into `flat_grads` (call zero_grad() first, as `optimizer.zero_grad()` at reference lib.py:578).
         `n_active` = nb: only the first nb samples of the batch carry a non-zero gradient (the dynamic-eval loss uses
         the augmented copies only, reference lib.py:570-575), so the backward runs on those samples; the skipped
-        samples would contribute exact zeros to every gradient."""
+        samples would contribute exact zeros to every gradient.
+        `input_grad=True` also returns dL/d(audio_signal) [B, F, T]; `param_grads=False` skips every weight-gradient
+        product (the entropy-gradient input perturbation, reference lib.py:96, needs only the input gradient)."""
+        self._skip_wgrad = not param_grads
+        try:
+            return self._backward(grad_posteriors, n_active, input_grad)
+        finally:
+            self._skip_wgrad = False
+
+    def _backward(self, grad_posteriors, n_active, input_grad):
         ctx = self._ctx
         if ctx is None:
             raise ops.DynError("backward() without a grad-mode forward")
@@ -367,11 +377,12 @@ class SCConformerXL:
             self._attn_bwd(dh, p + "attn", lc["attn"])
             self._ff_bwd(dh, p + "ff1", lc["ff1"])
             ctx["layers"][l] = None  # release this block's activations
-        self._sub_bwd(dh, ctx)
+        dx = self._sub_bwd(dh, ctx, input_grad)
         self._ctx = None
         for name, _ in self.spec:
             if not self.trainable(name):
                 self.G[name].zero_()
+        return dx
 
     def _ff_bwd(self, dh, p, saved):
         h, mean, rstd, n, u, a = saved
@@ -420,26 +431,37 @@ class SCConformerXL:
         else:
             ops.layernorm_bwd(c, P[p + ".cnorm.weight"], stats[0], stats[1], dnn, dc, G[p + ".cnorm.weight"],
                               G[p + ".cnorm.bias"], dx_beta=0.0)
-        if self.trainable(p + ".dw.weight"):
+        if self.trainable(p + ".dw.weight") and not self._skip_wgrad:
             ops.dwconv1d_wgrad(g, dc, G[p + ".dw.weight"], G[p + ".dw.bias"], beta=1.0)
         dg = ops.dwconv1d_dgrad(dc, P[p + ".dw.weight"])
         du = ops.glu_bwd(u, dg)
         dn = self._lin_bwd(du, n, p + ".pw1.weight", p + ".pw1.bias")
         ops.layernorm_bwd(h, P[p + ".norm.weight"], mean, rstd, dn, dh, G[p + ".norm.weight"], G[p + ".norm.bias"], dx_beta=1.0)
 
-    def _sub_bwd(self, dh, ctx):
-        if not self.trainable("subsampling."):
-            return
+    def _sub_bwd(self, dh, ctx, input_grad=False):
+        if not self.trainable("subsampling.") and not input_grad:
+            return None
         P, G = self.P, self.G
+        wg = self.trainable("subsampling.") and not self._skip_wgrad
         xt, z1, u2, z2, u3, z3, a3 = ctx["sub"]
         B, T, T3, F3 = ctx["dims"]
         C = self.config["subsampling_conv_channels"]
         da3 = self._lin_bwd(dh, a3.view(B, T3, F3 * C), "subsampling.out.weight", "subsampling.out.bias")
         dz3 = ops.silu_bwd(z3, da3.view_as(z3), out=da3.view_as(z3))
         du3 = self._lin_bwd(dz3, u3, "subsampling.pw3.weight", "subsampling.pw3.bias")
-        ops.dwconv2d_s2_wgrad(z2, du3, G["subsampling.dw3.weight"], G["subsampling.dw3.bias"], beta=1.0)
+        if wg:
+            ops.dwconv2d_s2_wgrad(z2, du3, G["subsampling.dw3.weight"], G["subsampling.dw3.bias"], beta=1.0)
         dz2 = ops.dwconv2d_s2_dgrad(z2, P["subsampling.dw3.weight"], du3)
         du2 = self._lin_bwd(dz2, u2, "subsampling.pw2.weight", "subsampling.pw2.bias")
-        ops.dwconv2d_s2_wgrad(z1, du2, G["subsampling.dw2.weight"], G["subsampling.dw2.bias"], beta=1.0)
+        if wg:
+            ops.dwconv2d_s2_wgrad(z1, du2, G["subsampling.dw2.weight"], G["subsampling.dw2.bias"], beta=1.0)
         dz1 = ops.dwconv2d_s2_dgrad(z1, P["subsampling.dw2.weight"], du2)
-        ops.conv2d_first_wgrad(xt, dz1, G["subsampling.conv1.weight"], G["subsampling.conv1.bias"], beta=1.0)
+        if wg:
+            ops.conv2d_first_wgrad(xt, dz1, G["subsampling.conv1.weight"], G["subsampling.conv1.bias"], beta=1.0)
+        if not input_grad:
+            return None
+        dxt = ops.conv2d_first_dgrad(dz1, P["subsampling.conv1.weight"], T, xt.shape[-1])      # [B, T, F]
+        dx = torch.empty(B, xt.shape[-1], T, device=dxt.device, dtype=torch.float32)
+        for b in range(B):
+            ops.transpose_ft(dxt[b], out=dx[b])                                                 # -> [B, F, T]
+        return dx

@@ -316,6 +316,25 @@ def log_softmax_bwd(y, dy, out=None):
     return out
 
 
+def entropy_grad(log_probs, scale):
+    """Gradient of `scale * sum_rows H(row)` w.r.t. log-probs [..., C]; returns (grad, per-row entropies)."""
+    _cc(log_probs, "entropy_grad.log_probs")
+    rows, L = _rows_L(log_probs)
+    g = torch.empty_like(log_probs)
+    ent = torch.empty(rows, device=log_probs.device, dtype=F32)
+    check(_L().dyn_entropy_grad(log_probs.data_ptr(), g.data_ptr(), ent.data_ptr(), rows, L, L, scale, _stream()), "dyn_entropy_grad")
+    return g, ent
+
+
+def conv2d_first_dgrad(dz, w, T, F):
+    """dz [B, To, Fo, C] -> dx [B, T, F] for the 1-channel 3x3/s2 first conv."""
+    _cc(dz, "conv2d_first_dgrad.dz"); _cc(w, "conv2d_first_dgrad.w")
+    B, C = dz.shape[0], dz.shape[-1]
+    dx = torch.empty(B, T, F, device=dz.device, dtype=F32)
+    check(_L().dyn_conv2d_first_dgrad(dz.data_ptr(), w.data_ptr(), dx.data_ptr(), B, T, F, C, _stream()), "dyn_conv2d_first_dgrad")
+    return dx
+
+
 # ----------------------------------------------------------------------------------------------- convolutions
 def dwconv1d(x, w, bias, out=None):
     """x [B, T, C] channels-last, w [C, KW]."""

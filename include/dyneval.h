@@ -104,6 +104,10 @@ int dyn_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, in
                     void* stream);
 int dyn_log_softmax_fwd(const float* x, float* y, int64_t rows, int64_t L, int64_t ldx, int64_t ldy, void* stream);
 int dyn_log_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int64_t L, int64_t ld, void* stream);
+/* Gradient of the mean categorical entropy w.r.t. the log-probabilities (the `entropy_augmentation` input perturbation,
+ * reference lcasr/lib.py:86-99): grad[r, c] = -p (y + H_r) * scale, H_r = -sum p y; entropy_per_row optional. */
+int dyn_entropy_grad(const float* log_probs, float* grad, float* entropy_per_row, int64_t rows, int64_t L, int64_t ld,
+                     float scale, void* stream);
 
 /* Depthwise Conv1d over time, channels-last x [B, T, C], w [C, KW], 'same' zero padding (conformer conv module,
  * `conv_kernel_size: 9`, yaml:15).  KW in {3,5,7,9,15,31}. */
@@ -122,6 +126,9 @@ int dyn_dwconv1d_wgrad(const float* x, const float* dy, float* dw, float* dbias,
  * The 1x1 pointwise convs between them are dyn_gemm_f32 calls. */
 int dyn_conv2d_first_fwd(const float* x, const float* w, const float* bias, float* z, int64_t B, int64_t T, int64_t F,
                          int64_t C, void* stream);
+/* input gradient of conv2d_first (needed only by the entropy-gradient input perturbation, reference lib.py:96) */
+int dyn_conv2d_first_dgrad(const float* dz, const float* w, float* dx, int64_t B, int64_t T, int64_t F, int64_t C,
+                           void* stream);
 int64_t dyn_conv2d_wgrad_workspace_bytes(int64_t B, int64_t To, int64_t C);
 int dyn_conv2d_first_wgrad(const float* x, const float* dz, float* dw, float* dbias, float beta, int64_t B, int64_t T,
                            int64_t F, int64_t C, void* workspace, int64_t workspace_bytes, void* stream);
@@ -144,6 +151,16 @@ int dyn_specaug_freqmask(float* x, int64_t F, int64_t T, const int32_t* f0, cons
                          float value, void* stream);
 int dyn_specaug_timemask(float* x, int64_t F, int64_t T, const int32_t* t0, const int32_t* width, int64_t n_masks,
                          float value, void* stream);
+
+/* Optional Loop-A augmentations on a device-resident [F, T] window (random draws stay on the host):
+ *   dyn_gather_frames  frame_shuffle (reference lcasr/lib.py:81-84): y = x[:, index] (along_time) or x[index, :]
+ *   dyn_moments        (sum, mean, unbiased std) of a buffer — spec.std() of add_random_noise (lib.py:379-382)
+ *   dyn_cutout         cutout (lib.py:384-417): rects [n, 4] = (y0, y1, x0, x1); mode 0 zero, 1 own mean, 2 constant */
+int dyn_gather_frames(const float* x, const int32_t* index, float* y, int64_t F, int64_t T, int32_t along_time, void* stream);
+int64_t dyn_moments_workspace_bytes(void);
+int dyn_moments(const float* x, int64_t n, float* out3, void* workspace, int64_t workspace_bytes, void* stream);
+int dyn_cutout(float* x, int64_t F, int64_t T, const int32_t* rects, int64_t n_rects, int32_t mode, float value,
+               float* means_scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CTC.  dyn_ctc_greedy replaces GreedyCTCDecoder on a CPU copy of the posteriors (reference lcasr/lib.py:498,

@@ -99,10 +99,10 @@ def test_optional_augmentations_refuse_instead_of_silently_skipping():
 
     class M:
         device = torch.device("cuda:0")
-    a = argparse.Namespace(config={'model': {'subsampling_factor': 8}, 'audio_chunking': {'size': 1, 'overlap': 0}, 'training': {}},
-                           random_noise=0.1)
-    with pytest.raises(NotImplementedError):
-        lib.dynamic_eval(a, M(), torch.zeros(1, 80, 10), 8, 0, None)
+    a = argparse.Namespace(config={"model": {"subsampling_factor": 8}, "audio_chunking": {"size": 1, "overlap": 0}, "training": {}},
+                           lm_tta_beams=3)
+    with pytest.raises(NotImplementedError):   # LM beam-search pseudo-labels need the un-vendored `lming` LM
+        lib.dynamic_eval(a, M(), torch.zeros(1, 80, 10), 8, 0, None, beam_search_fn=object())
 
 
 # ------------------------------------------------------------------------------------------------ host utilities

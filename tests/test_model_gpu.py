@@ -176,3 +176,22 @@ def test_adapt_on_concat_only_matches_loop_a(cuda):
         assert (a - b).abs().max().item() < 5e-5
     with pytest.raises(ValueError):
         concatenate_specs([])
+
+
+def test_entropy_augmentation_matches_autograd(cuda):
+    """reference lcasr/lib.py:86-99: spec + 0.001 * d mean-entropy / d spec, computed by torch autograd on the oracle."""
+    from dynamic_asr_eval_amd import lib
+    ref, hip = _pair(cuda, SMALL, vocab=128, seed=17)
+    spec = torch.randn(1, 80, 200, generator=torch.Generator().manual_seed(5))
+    audio = spec.clone().requires_grad_()
+    lp = ref(audio_signal=audio)['final_posteriors']
+    entropy = torch.distributions.Categorical(probs=lp.exp()).entropy()
+    grad = torch.autograd.grad(outputs=entropy.mean(), inputs=audio, create_graph=False)[0] * 0.001
+    expect = (audio + grad).detach()
+    got = lib.entropy_augmentation(spec.to(cuda).clone(), hip, enabled=True)
+    delta_ref = (expect - spec)
+    delta = (got.cpu() - spec)
+    assert delta_ref.abs().max() > 0
+    rel = (delta - delta_ref).abs().max().item() / delta_ref.abs().max().item()
+    assert rel < 2e-3, rel
+    assert torch.equal(lib.entropy_augmentation(spec.to(cuda), hip, enabled=False).cpu(), spec)

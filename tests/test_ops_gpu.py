@@ -270,3 +270,21 @@ def test_stitch(cuda):
     n = int((rc.sum(-1) != 0).sum())
     out = ops.stitch_finalize(acc, cnt, n)
     _close(out, torch.log(ra[:n] / rc[:n]), 2e-6, "stitch")
+
+
+def test_optional_augmentations_match_reference_functions(cuda):
+    """frame_shuffle / add_random_noise / cutout (reference lcasr/lib.py:81-84,379-417) with the same torch RNG stream."""
+    from dynamic_asr_eval_amd import augment
+    from oracle import augment_ref as R
+    spec = torch.randn(1, 80, 600, generator=_g(80)) * 1.7 + 0.2
+    for kw in (dict(time_dimension=True), dict(freq_dimension=True), dict(time_dimension=True, freq_dimension=True)):
+        torch.manual_seed(5); ref = R.frame_shuffle(spec.clone(), **kw)
+        torch.manual_seed(5); got = augment.frame_shuffle(spec[0].to(cuda).clone(), **kw)
+        _close(got, ref[0], 0.0, f"frame_shuffle {kw}")
+    torch.manual_seed(6); ref = R.add_random_noise(spec.clone(), 0.3)
+    torch.manual_seed(6); got = augment.add_random_noise(spec[0].to(cuda).clone(), 0.3)
+    _close(got, ref[0], 2e-5, "add_random_noise")
+    for val in ("mean", "mean_recording", "zero"):
+        torch.manual_seed(7); ref = R.cutout(spec.clone(), 600, cutout_val=val, num_rectangles=7, max_width=100, max_height=10)
+        torch.manual_seed(7); got = augment.cutout(spec[0].to(cuda).clone(), 600, cutout_val=val, num_rectangles=7, max_width=100, max_height=10)
+        _close(got, ref[0], 2e-6, f"cutout {val}")
