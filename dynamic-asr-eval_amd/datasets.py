@@ -46,3 +46,35 @@ def get_text_and_audio_synthetic(split, durations_s=None, seed=1234):
 
 
 datasets_functions = {'synthetic': get_text_and_audio_synthetic}
+
+
+# ---- synthetic recordings that start from a WAVEFORM and go through the on-device log-mel front end
+def synthetic_waveform(seconds, seed, sample_rate=16000):
+    g = torch.Generator().manual_seed(int(seed))
+    n = int(seconds * sample_rate)
+    t = torch.arange(n, dtype=torch.float32) / sample_rate
+    wav = 0.05 * torch.randn(n, generator=g)
+    for f0 in (220.0, 440.0, 1250.0, 3100.0):
+        wav += 0.1 * torch.sin(2 * torch.pi * f0 * t) * (0.5 + 0.5 * torch.sin(2 * torch.pi * t / (3.0 + f0 / 1000.0)))
+    return wav
+
+
+_FRONTEND = {}
+
+
+def _process_wave(rec):
+    from .frontend import LogMel
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lm = _FRONTEND.setdefault(dev.index, LogMel(dev))
+    return lm(synthetic_waveform(rec['seconds'], rec['seed'])), rec['text']
+
+
+def get_text_and_audio_synthetic_wave(split, durations_s=None, seed=4321):
+    assert split in ('test', 'dev')
+    durations_s = durations_s or ([3600] * 6 if split == 'test' else [900] * 4)
+    return [{'id': f'synthetic_wave_{split}_{i:03d}', 'text': synthetic_text(max(1, int(d * 2.5)), seed + i), 'audio': None,
+             'seconds': d, 'frames': 1 + int(d * 16000) // 160, 'seed': seed + i, 'process_fn': _process_wave}
+            for i, d in enumerate(durations_s)]
+
+
+datasets_functions['synthetic_wave'] = get_text_and_audio_synthetic_wave

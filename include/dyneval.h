@@ -152,6 +152,18 @@ int dyn_specaug_freqmask(float* x, int64_t F, int64_t T, const int32_t* f0, cons
 int dyn_specaug_timemask(float* x, int64_t F, int64_t T, const int32_t* t0, const int32_t* width, int64_t n_masks,
                          float value, void* stream);
 
+/* Log-mel front end (upstream lcasr.utils.audio_tools.processing_chain, called by the dataset adapters: reference
+ * lcasr/earnings22/run.py:61, tedlium/run.py:94, chime6/run.py:61-68).  The STFT itself is a dyn_gemm_f32 call on the
+ * reflect-padded signal with lda = hop < K (overlapping rows) and a window-folded DFT basis; these are the passes
+ * around it:  reflect pad -> [GEMM: re|im] -> power -> [GEMM: mel] -> log + per-bin (mean, std) -> normalise + transpose.
+ *   dyn_stft_power     reim [T, 2*KP] (re | im) -> power [T, KP]
+ *   dyn_logmel_finish  mel [T, F] (overwritten by log(mel + eps)) -> out [F, T], optionally per-bin normalised over T */
+int dyn_reflect_pad(const float* x, float* out, int64_t n, int64_t pad, void* stream);
+int dyn_stft_power(const float* reim, float* power, int64_t T, int64_t KP, void* stream);
+int64_t dyn_logmel_finish_workspace_bytes(int64_t T, int64_t F);
+int dyn_logmel_finish(float* mel, float* out, int64_t T, int64_t F, float eps, int32_t normalize, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+
 /* Optional Loop-A augmentations on a device-resident [F, T] window (random draws stay on the host):
  *   dyn_gather_frames  frame_shuffle (reference lcasr/lib.py:81-84): y = x[:, index] (along_time) or x[index, :]
  *   dyn_moments        (sum, mean, unbiased std) of a buffer — spec.std() of add_random_noise (lib.py:379-382)

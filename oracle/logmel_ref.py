@@ -1,0 +1,31 @@
+"""ORACLE (test infrastructure only).  torch CPU restatement of the log-mel front end defined in
+dynamic-asr-eval_amd/frontend.py (the upstream `lcasr.utils.audio_tools.processing_chain` called at reference
+lcasr/earnings22/run.py:61 is un-vendored and absent — PARITY UNPINNED against it): torch.stft(n_fft 512, hop 160,
+Hann(400), center, reflect) -> |X|^2 -> 80 HTK-mel filters (torchaudio melscale_fbanks rule) -> log(mel + 1e-6) ->
+per-bin (mean, unbiased std) normalisation over time."""
+import math
+
+import torch
+
+
+def mel_filterbank(n_freqs=257, f_min=0.0, f_max=8000.0, n_mels=80, sample_rate=16000):
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs, dtype=torch.float64)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2, dtype=torch.float64)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    return torch.clamp(torch.min((-1.0 * slopes[:, :-2]) / f_diff[:-1], slopes[:, 2:] / f_diff[1:]), min=0.0)
+
+
+def logmel_ref(waveform, eps=1e-6, normalize=True, dtype=torch.float64):
+    x = torch.as_tensor(waveform).reshape(-1).to(dtype)
+    X = torch.stft(x, n_fft=512, hop_length=160, win_length=400, window=torch.hann_window(400, periodic=True, dtype=dtype),
+                   center=True, pad_mode="reflect", return_complex=True)          # [257, T]
+    power = X.real ** 2 + X.imag ** 2
+    mel = mel_filterbank().to(dtype).T @ power                                    # [80, T]
+    lm = torch.log(mel + eps)
+    if normalize:
+        lm = (lm - lm.mean(-1, keepdim=True)) / lm.std(-1, keepdim=True)
+    return lm.unsqueeze(0)
