@@ -134,10 +134,10 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
 
 // Forward scan: alpha[b][t][s]; nll[b].  One workgroup per sample, ITEMS lattice positions per thread.
 template <int ITEMS>
-__global__ __launch_bounds__(SCAN_T) void ctc_alpha_kernel(const float* __restrict__ slab, const int32_t* __restrict__ targets,
-                                                            const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
-                                                            float* __restrict__ alpha, float* __restrict__ nll, CtcDims d) {
-    extern __shared__ __attribute__((aligned(16))) float rows[];  // 2 * L_max
+__device__ __forceinline__ void ctc_alpha_body(float* rows, const float* __restrict__ slab, const int32_t* __restrict__ targets,
+                                               const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
+                                               float* __restrict__ alpha, float* __restrict__ nll, const CtcDims& d) {
+    const int SCAN_T = blockDim.x;
     const int64_t b = blockIdx.x;
     const int T = ilen[b], S = tlen[b], L = 2 * S + 1;
     const int32_t* tg = targets + b * d.S_max;
@@ -201,10 +201,10 @@ __global__ __launch_bounds__(SCAN_T) void ctc_alpha_kernel(const float* __restri
 
 // Backward scan: beta recursion; overwrites alpha[b][t][s] with alpha + beta.
 template <int ITEMS>
-__global__ __launch_bounds__(SCAN_T) void ctc_beta_kernel(const float* __restrict__ slab, const int32_t* __restrict__ targets,
-                                                           const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
-                                                           float* __restrict__ alpha, CtcDims d) {
-    extern __shared__ __attribute__((aligned(16))) float rows[];
+__device__ __forceinline__ void ctc_beta_body(float* rows, const float* __restrict__ slab, const int32_t* __restrict__ targets,
+                                              const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
+                                              float* __restrict__ alpha, const CtcDims& d) {
+    const int SCAN_T = blockDim.x;
     const int64_t b = blockIdx.x;
     const int T = ilen[b], S = tlen[b], L = 2 * S + 1;
     if (T <= 0) return;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(SCAN_T) void ctc_beta_kernel(const float* __restric
             float v = -INFINITY;
             if (s == L - 1 || s == L - 2) v = sl[(int64_t)(T - 1) * d.L_max + s];
             prev[s] = v;
-            al[(int64_t)(T - 1) * d.L_max + s] += v;
+            al[(int64_t)(T - 1) * d.L_max + s] = v;
         }
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(SCAN_T) void ctc_beta_kernel(const float* __restric
                         const float c = skip[j] ? prev[s + 2] : -INFINITY;
                         const float v = lse3(a, bb, c) + lpv;
                         cur[s] = v;
-                        al[(int64_t)t * d.L_max + s] += v;
+                        al[(int64_t)t * d.L_max + s] = v;
                     }
                 }
                 __syncthreads();
@@ -259,11 +259,24 @@ __global__ __launch_bounds__(SCAN_T) void ctc_beta_kernel(const float* __restric
     }
 }
 
+// Both scans are independent until the gradient combines them, so they run as ONE launch: blockIdx.y = 0 walks alpha
+// forward, blockIdx.y = 1 walks beta backward, each on its own CU (halves the serial latency of the CTC step).
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void ctc_scan_kernel(const float* __restrict__ slab, const int32_t* __restrict__ targets,
+                                                         const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
+                                                         float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ nll,
+                                                         CtcDims d) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];  // 2 * L_max
+    if (blockIdx.y == 0) ctc_alpha_body<ITEMS>(rows, slab, targets, ilen, tlen, alpha, nll, d);
+    else ctc_beta_body<ITEMS>(rows, slab, targets, ilen, tlen, beta, d);
+}
+
 // grad[t, b, c] = (exp(lp) - exp(lcab[c] + nll - lp)) * g_b, lcab[c] = log sum_{s: label(s) = c} exp(alpha+beta)[t, s].
 // One workgroup per (t, b): all classes get exp(lp) * g, then the classes that occur in the target are corrected:
 // blank by a fixed-order block reduction over the even lattice positions, every other label by the thread that owns
 // its FIRST occurrence walking the next_same chain in increasing s (deterministic).
-__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ lp, const float* __restrict__ ab,
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ lp, const float* __restrict__ alpha_,
+                                                        const float* __restrict__ beta_,
                                                         const int32_t* __restrict__ targets, const int32_t* __restrict__ next_same,
                                                         const int32_t* __restrict__ is_first, const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
                                                         const float* __restrict__ nll, float* __restrict__ grad, int64_t g_st,
@@ -279,18 +292,19 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     float g = grad_scale;
     if (mean_reduction) g = grad_scale / ((float)(S > 0 ? S : 1) * (float)d.B);
     const float* row = lp + t * d.lp_st + b * d.lp_sb;
-    const float* abr = ab + (b * d.T_max + t) * d.L_max;
+    const float* ar = alpha_ + (b * d.T_max + t) * d.L_max;
+    const float* br = beta_ + (b * d.T_max + t) * d.L_max;
     const int32_t* tg = targets + b * d.S_max;
     const int32_t* nx = next_same + b * d.S_max;
     const float nl = nll[b];
     for (int c = threadIdx.x; c < d.C; c += blockDim.x) gr[c] = expf(row[c]) * g;
     // blank: positions 0, 2, ..., 2S
     float m = -INFINITY;
-    for (int k = threadIdx.x; k <= S; k += blockDim.x) m = fmaxf(m, abr[2 * k]);
+    for (int k = threadIdx.x; k <= S; k += blockDim.x) m = fmaxf(m, ar[2 * k] + br[2 * k]);
     m = dyn::block_max(m, red);
     float sum = 0.f;
     if (m != -INFINITY)
-        for (int k = threadIdx.x; k <= S; k += blockDim.x) sum += expf(abr[2 * k] - m);
+        for (int k = threadIdx.x; k <= S; k += blockDim.x) sum += expf(ar[2 * k] + br[2 * k] - m);
     sum = dyn::block_sum(sum, red);  // also orders the exp(lp)*g stores before the corrections below
     if (threadIdx.x == 0) {
         const float lpb = row[d.blank];
@@ -302,10 +316,10 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         if (!is_first[b * d.S_max + k]) continue;
         const int c = tg[k];
         float mm = -INFINITY;
-        for (int j = k; j >= 0; j = nx[j]) mm = fmaxf(mm, abr[2 * j + 1]);
+        for (int j = k; j >= 0; j = nx[j]) mm = fmaxf(mm, ar[2 * j + 1] + br[2 * j + 1]);
         float ss = 0.f;
         if (mm != -INFINITY)
-            for (int j = k; j >= 0; j = nx[j]) ss += expf(abr[2 * j + 1] - mm);
+            for (int j = k; j >= 0; j = nx[j]) ss += expf(ar[2 * j + 1] + br[2 * j + 1] - mm);
         const float lcab = (mm == -INFINITY) ? -INFINITY : logf(ss) + mm;
         const float lpc = row[c];
         gr[c] = (expf(lpc) - expf(lcab + nl - lpc)) * g;
@@ -326,7 +340,7 @@ __global__ void ctc_loss_reduce_kernel(const float* __restrict__ nll, const int3
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct CtcWs {
-    float* slab; float* alpha; float* nll; int32_t* next_same; int32_t* is_first;
+    float* slab; float* alpha; float* beta; float* nll; int32_t* next_same; int32_t* is_first;
     int64_t total;
 };
 
@@ -337,6 +351,7 @@ CtcWs carve(void* ws, int64_t T, int64_t B, int64_t S_max) {
     int64_t off = 0;
     w.slab = (float*)(p + off); off += align_up(B * T * L * 4, 256);
     w.alpha = (float*)(p + off); off += align_up(B * T * L * 4, 256);
+    w.beta = (float*)(p + off); off += align_up(B * T * L * 4, 256);
     w.nll = (float*)(p + off); off += align_up(B * 4, 256);
     w.next_same = (int32_t*)(p + off); off += align_up((B * S_max + 1) * 4, 256);
     w.is_first = (int32_t*)(p + off); off += align_up((B * S_max + 1) * 4, 256);
@@ -385,23 +400,23 @@ extern "C" int dyn_ctc_loss(const float* log_probs, int64_t T, int64_t B, int64_
     hipLaunchKernelGGL(ctc_prep_kernel, dim3((unsigned)B), dim3(256), 0, st, targets, target_lengths, w.next_same, w.is_first, Sm);
     hipLaunchKernelGGL(ctc_gather_kernel, dim3((unsigned)T, (unsigned)B), dim3(256), 0, st, log_probs, targets, input_lengths,
                        target_lengths, w.slab, d);
-    const int items = (int)dyn::cdiv(L, SCAN_T);
+    int threads = (int)((L + 63) / 64 * 64);
+    if (threads > SCAN_T) threads = SCAN_T;
+    const int items = (int)dyn::cdiv(L, threads);
     const size_t shm = (size_t)2 * L * sizeof(float);
-#define GO_A(I) hipLaunchKernelGGL((ctc_alpha_kernel<I>), dim3((unsigned)B), dim3(SCAN_T), shm, st, w.slab, targets, input_lengths, target_lengths, w.alpha, w.nll, d)
-#define GO_B(I) hipLaunchKernelGGL((ctc_beta_kernel<I>), dim3((unsigned)B), dim3(SCAN_T), shm, st, w.slab, targets, input_lengths, target_lengths, w.alpha, d)
-    if (items <= 1) GO_A(1); else if (items <= 2) GO_A(2); else if (items <= 4) GO_A(4); else GO_A(8);
+    const dim3 sgrid((unsigned)B, grad ? 2u : 1u);
+#define GO_S(I) hipLaunchKernelGGL((ctc_scan_kernel<I>), sgrid, dim3(threads), shm, st, w.slab, targets, input_lengths, target_lengths, w.alpha, w.beta, w.nll, d)
+    if (items <= 1) GO_S(1); else if (items <= 2) GO_S(2); else if (items <= 4) GO_S(4); else GO_S(8);
     hipLaunchKernelGGL(ctc_loss_reduce_kernel, dim3(1), dim3(64), 0, st, w.nll, target_lengths, loss, B, (int)reduction);
     if (nll_per_sample) {
         hipError_t e = hipMemcpyAsync(nll_per_sample, w.nll, B * sizeof(float), hipMemcpyDeviceToDevice, st);
         DYN_REQUIRE(e == hipSuccess, DYN_E_LAUNCH, "dyn_ctc_loss: copy of per-sample nll failed");
     }
     if (grad) {
-        if (items <= 1) GO_B(1); else if (items <= 2) GO_B(2); else if (items <= 4) GO_B(4); else GO_B(8);
-        hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)T, (unsigned)B), dim3(256), 0, st, log_probs, w.alpha, targets,
+        hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)T, (unsigned)B), dim3(256), 0, st, log_probs, w.alpha, w.beta, targets,
                            w.next_same, w.is_first, input_lengths, target_lengths, w.nll, grad, g_stride_t, g_stride_b, grad_scale,
                            (int)reduction, d);
     }
-#undef GO_A
-#undef GO_B
+#undef GO_S
     return dyn::check_launch("dyn_ctc_loss");
 }

@@ -4,6 +4,7 @@
 // Reference call sites: the activation / residual / bias ops inside model(audio_signal=...) and
 // loss.backward() (reference lcasr/lib.py:550,579); SpecAugment frequency masks (lib.py:541).
 #include "common.h"
+#include "reduce.h"
 
 namespace {
 
@@ -201,8 +202,8 @@ extern "C" int dyn_axpby(const float* x, float* y, float a, float b, int64_t n, 
 }
 
 extern "C" int64_t dyn_colsum_workspace_bytes(int64_t rows, int64_t C) {
-    int64_t chunks = dyn::cdiv(rows, 256);
-    if (chunks > 256) chunks = 256;
+    int64_t chunks = dyn::cdiv(rows, 32);
+    if (chunks > 512) chunks = 512;
     if (chunks < 1) chunks = 1;
     return chunks * C * (int64_t)sizeof(float);
 }
@@ -210,8 +211,8 @@ extern "C" int64_t dyn_colsum_workspace_bytes(int64_t rows, int64_t C) {
 extern "C" int dyn_colsum(const float* x, float* out, int64_t rows, int64_t C, float beta, void* workspace,
                           int64_t workspace_bytes, void* stream) {
     DYN_REQUIRE(rows >= 0 && C > 0 && x && out, DYN_E_ARG, "dyn_colsum: bad arguments");
-    int64_t chunks = dyn::cdiv(rows, 256);
-    if (chunks > 256) chunks = 256;
+    int64_t chunks = dyn::cdiv(rows, 32);
+    if (chunks > 512) chunks = 512;
     if (chunks < 1) chunks = 1;
     DYN_REQUIRE(workspace && workspace_bytes >= chunks * C * (int64_t)sizeof(float), DYN_E_WORKSPACE,
                 "dyn_colsum: workspace too small");
@@ -219,7 +220,7 @@ extern "C" int dyn_colsum(const float* x, float* out, int64_t rows, int64_t C, f
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)dyn::cdiv(C, 64), (unsigned)chunks), dim3(256), 0, st, x,
                        (float*)workspace, rows, (int)C, rpc);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(C)), dim3(TPB), 0, st, (const float*)workspace, out, chunks, C, beta);
+    dyn::launch_reduce_partials((const float*)workspace, out, chunks, C, beta, st);
     return dyn::check_launch("dyn_colsum");
 }
 
