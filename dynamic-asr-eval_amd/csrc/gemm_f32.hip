@@ -499,7 +499,7 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
     if (d->M == 0 || d->N == 0) return DYN_OK;
     DYN_REQUIRE(d->A && d->B && d->C, DYN_E_ARG, "dyn_gemm_f32: null operand");
     // lda < K is allowed for a non-transposed A: overlapping rows = frames of a 1-D signal (the STFT as an implicit GEMM)
-    DYN_REQUIRE(d->lda >= (d->trans_a ? d->M : 1) && d->ldb >= (d->trans_b ? d->K : d->N) && d->ldc >= d->N,
+    DYN_REQUIRE(d->lda >= (d->trans_a ? d->M : 1) && d->ldb >= (d->trans_b ? d->K : 1) && d->ldc >= d->N,
                 DYN_E_ARG, "dyn_gemm_f32: leading dimension smaller than the row length");
     Plan pl = make_plan(d);
     const int64_t need = pl.ws_bytes > pl.tail_ws_bytes ? pl.ws_bytes : pl.tail_ws_bytes;

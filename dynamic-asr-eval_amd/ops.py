@@ -501,3 +501,121 @@ def stitch_finalize(acc, count, rows):
     out = torch.empty(rows, C, device=acc.device, dtype=F32)
     check(_L().dyn_stitch_finalize(acc.data_ptr(), count.data_ptr(), out.data_ptr(), rows, C, _stream()), "dyn_stitch_finalize")
     return out
+
+
+# ----------------------------------------------------------------------------------------------- wav2vec2 pieces
+def gelu(x, out=None):
+    _c(x, "gelu.x")
+    out = torch.empty_like(x) if out is None else out
+    check(_L().dyn_gelu_fwd(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "dyn_gelu_fwd")
+    return out
+
+
+def gelu_bwd(x, dy, out=None):
+    _c(x, "gelu_bwd.x"); _c(dy, "gelu_bwd.dy")
+    out = torch.empty_like(x) if out is None else out
+    check(_L().dyn_gelu_bwd(x.data_ptr(), dy.data_ptr(), out.data_ptr(), x.numel(), _stream()), "dyn_gelu_bwd")
+    return out
+
+
+def colnorm(x, gamma, beta, eps=1e-5):
+    """x [B, T, C]: normalise over T per (b, c) (GroupNorm with groups == channels). Returns (y, mean, rstd)."""
+    _c(x, "colnorm.x")
+    B, T, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(B, C, device=x.device, dtype=F32); rstd = torch.empty(B, C, device=x.device, dtype=F32)
+    ws = workspace(x.device)
+    check(_L().dyn_colnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, T, C,
+                               eps, ws.data_ptr(), ws.numel(), _stream()), "dyn_colnorm_fwd")
+    return y, mean, rstd
+
+
+def colnorm_bwd(x, gamma, mean, rstd, dy, dgamma, dbeta, wgrad_beta=1.0):
+    B, T, C = x.shape
+    dx = torch.empty_like(x)
+    ws = workspace(x.device)
+    check(_L().dyn_colnorm_bwd(x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(),
+                               _opt(dgamma, "dgamma"), _opt(dbeta, "dbeta"), wgrad_beta, B, T, C, ws.data_ptr(), ws.numel(), _stream()),
+          "dyn_colnorm_bwd")
+    return dx
+
+
+def conv1d_out_len(T, kw, stride):
+    return (T - kw) // stride + 1
+
+
+def conv1d(x, w, kw, stride):
+    """Valid strided Conv1d as an implicit GEMM: x [B, T, Cin] channels-last, w [Cout, kw*Cin] -> [B, Tout, Cout]."""
+    _c(x, "conv1d.x"); _c(w, "conv1d.w")
+    B, T, Cin = x.shape
+    Cout = w.shape[0]
+    Tout = conv1d_out_len(T, kw, stride)
+    y = torch.empty(B, Tout, Cout, device=x.device, dtype=F32)
+    gemm(x, w, y, trans_b=True, M=Tout, N=Cout, K=kw * Cin, lda=stride * Cin, ldb=kw * Cin, ldc=Cout, nb1=B,
+         sa=(T * Cin, 0), sc=(Tout * Cout, 0))
+    return y
+
+
+def conv1d_wgrad(x, dy, dw, kw, stride, beta=1.0):
+    """dw [Cout, kw*Cin] = beta*dw + sum_b dy[b]^T @ rows(x[b])  (rows overlap: ldb = stride*Cin < kw*Cin)."""
+    B, T, Cin = x.shape
+    Tout, Cout = dy.shape[1], dy.shape[2]
+    for b in range(B):
+        gemm(dy, x, dw, trans_a=True, M=Cout, N=kw * Cin, K=Tout, lda=Cout, ldb=stride * Cin, ldc=kw * Cin,
+             a_off=b * Tout * Cout, b_off=b * T * Cin, beta=beta if b == 0 else 1.0)
+    return dw
+
+
+def conv1d_dgrad(dy, w, T, Cin, kw, stride):
+    """dx [B, T, Cin] from dy [B, Tout, Cout]: dense row gradients (GEMM) then col2im over the overlapping rows."""
+    B, Tout, Cout = dy.shape
+    dA = torch.empty(B, Tout, kw * Cin, device=dy.device, dtype=F32)
+    gemm(dy, w, dA, M=B * Tout, N=kw * Cin, K=Cout, lda=Cout, ldb=kw * Cin, ldc=kw * Cin)
+    dx = torch.empty(B, T, Cin, device=dy.device, dtype=F32)
+    check(_L().dyn_col2im_1d(dA.data_ptr(), dx.data_ptr(), B, T, Tout, Cin, kw, stride, _stream()), "dyn_col2im_1d")
+    return dx
+
+
+def weight_norm(v, g):
+    """v [rows, kw, cg], g [kw] -> w = g[tap] * v / ||v[:, tap, :]||."""
+    rows, kw, cg = v.shape
+    w = torch.empty_like(v)
+    ws = workspace(v.device)
+    check(_L().dyn_weight_norm_fwd(v.data_ptr(), g.data_ptr(), w.data_ptr(), rows, kw, cg, ws.data_ptr(), ws.numel(), _stream()),
+          "dyn_weight_norm_fwd")
+    return w
+
+
+def weight_norm_bwd(v, g, dw, dv, dg, beta=1.0):
+    rows, kw, cg = v.shape
+    ws = workspace(v.device)
+    check(_L().dyn_weight_norm_bwd(v.data_ptr(), g.data_ptr(), dw.data_ptr(), dv.data_ptr(), dg.data_ptr(), beta, rows, kw, cg,
+                                   ws.data_ptr(), ws.numel(), _stream()), "dyn_weight_norm_bwd")
+
+
+def group_pack(x, G, pad):
+    B, T, C = x.shape
+    xg = torch.empty(B, G, T + 2 * pad, C // G, device=x.device, dtype=F32)
+    check(_L().dyn_group_pack(x.data_ptr(), xg.data_ptr(), B, T, C, G, pad, _stream()), "dyn_group_pack")
+    return xg
+
+
+def group_unpack(yg, bias, T, C):
+    B, G, Tg, cg = yg.shape
+    y = torch.empty(B, T, C, device=yg.device, dtype=F32)
+    check(_L().dyn_group_unpack(yg.data_ptr(), y.data_ptr(), _opt(bias, "bias"), B, T, Tg, C, G, _stream()), "dyn_group_unpack")
+    return y
+
+
+def group_pack_grad(dy, G, Tg):
+    B, T, C = dy.shape
+    dyg = torch.empty(B, G, Tg, C // G, device=dy.device, dtype=F32)
+    check(_L().dyn_group_pack_grad(dy.data_ptr(), dyg.data_ptr(), B, T, Tg, C, G, _stream()), "dyn_group_pack_grad")
+    return dyg
+
+
+def group_unpack_grad(dxg, dx, pad, beta=0.0):
+    B, T, C = dx.shape
+    G = dxg.shape[1]
+    check(_L().dyn_group_unpack_grad(dxg.data_ptr(), dx.data_ptr(), B, T, C, G, pad, beta, _stream()), "dyn_group_unpack_grad")
+    return dx

@@ -1,0 +1,171 @@
+"""Drop-in mirror of the reference's wav2vec2 dynamic-eval library (reference wav2vec2/lib.py) on the HIP path:
+`dynamic_eval_ctc_loss_su` / `dynamic_eval_su` (:293-462, the loop `wav2vec2/tedlium/run.py:155` drives) and the chunked
+`dynamic_eval_ctc_loss` / `dynamic_eval` (:41-235), plus `disable_dropout` (:34-38).
+
+Same call signatures; `model` is this package's Wav2Vec2ForCTC (wav2vec2_model.py), `processor` may be None: the only
+thing the reference uses it for is `processor.feature_extractor(...)` = zero-mean / unit-variance normalisation of each
+waveform (eps 1e-7), which runs here as a HIP kernel on the device (dyn_colnorm_fwd with one channel).
+The WavAugment effects of the chunked variant (`augment.EffectChain`, un-vendored and absent; lib.py:131-143) are not
+available: the chunked loop runs with clean copies, as the per-utterance variant does in the reference itself."""
+import random
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from .decoding import GreedyCTCDecoder
+from .optim import MADGRAD, Adam  # noqa: F401
+
+try:
+    from tqdm import tqdm
+except Exception:  # pragma: no cover
+    def tqdm(x, **_):
+        return x
+
+
+class CharTokenizer:
+    """Stand-in for the HF Wav2Vec2CTCTokenizer of wav2vec2-base-960h (needs downloaded files): same 32-symbol layout
+    (<pad>=0 is the CTC blank, <s>, </s>, <unk>, '|' word delimiter, then letters and apostrophe), `blank_id`,
+    `vocab_size`, `decode(ids) -> str`, `tokenizer(text).input_ids`."""
+    SYMBOLS = ["<pad>", "<s>", "</s>", "<unk>", "|"] + list("ETAONIHSRDLUMWCFGYPBVK'XJQZ")
+
+    def __init__(self):
+        self.vocab = {s: i for i, s in enumerate(self.SYMBOLS)}
+        self.blank_id = 0
+        self.vocab_size = len(self.SYMBOLS)
+
+    def decode(self, ids):
+        return "".join(" " if self.SYMBOLS[i] == "|" else self.SYMBOLS[i] for i in ids if i > 3 or i == 3)
+
+    def __call__(self, text):
+        ids = [self.vocab["|"] if ch == " " else self.vocab.get(ch, 3) for ch in text if ch == " " or ch in self.vocab or True]
+        return SimpleNamespace(input_ids=ids)
+
+
+def disable_dropout(model):
+    """reference wav2vec2/lib.py:34-38 — our model has no dropout modules (eval-mode forward)."""
+    return model
+
+
+def normalize_waveform(x):
+    """processor.feature_extractor(...) of the reference (lib.py:161,406) on the device: per-row zero mean / unit variance."""
+    B, L = x.shape
+    ones = torch.ones(1, device=x.device, dtype=torch.float32)
+    zeros = torch.zeros(1, device=x.device, dtype=torch.float32)
+    y, _, _ = ops.colnorm(x.contiguous().view(B, L, 1), ones, zeros, eps=1e-7)
+    return y.view(B, L)
+
+
+def _snapshot(model):
+    return model.flat_params.clone()
+
+
+def dynamic_eval_ctc_loss_su(args, model, utterances, seq_len, overlap, tokenizer, processor, use_tqdm=True, optim=MADGRAD,
+                             num_negatives=1, lr_args={'lr': 1e-15}, ngram_decoder=None):
+    """reference wav2vec2/lib.py:293-462"""
+    if ngram_decoder is not None:
+        raise NotImplementedError("n-gram (pyctcdecode) pseudo-labels need the un-vendored decoder and its ARPA file")
+    device = model.device
+    downsampling_factor = 4
+    original = _snapshot(model)
+    blank = tokenizer.blank_id
+    optimizer = optim(model.parameters(), **lr_args)
+    decoder = GreedyCTCDecoder(tokenizer=tokenizer, blank_id=blank, device=device)
+    assert overlap / downsampling_factor == overlap // downsampling_factor, 'Overlap must be a multiple of the downsampling factor'
+    model = disable_dropout(model)
+    for epoch in range(args.__dict__.get('epochs', 1)):
+        indexes = list(range(len(utterances)))
+        indexes = random.sample(indexes, len(indexes)) if args.__dict__.get('shuffle', False) else indexes
+        pbar = tqdm(indexes) if use_tqdm else indexes
+        for idx in pbar:
+            wav = utterances[idx]['waveform'].to(device=device, dtype=torch.float32)            # [1, L]
+            audio_chunk = wav.reshape(1, -1).repeat(num_negatives + 1, 1).contiguous()          # [B, L]
+            input_values = normalize_waveform(audio_chunk)
+            with torch.enable_grad():
+                logits = model(input_values).logits
+            log_p = ops.log_softmax(logits)                                                      # F.log_softmax, lib.py:417
+            pseudo_targets = decoder(log_p[-1])
+            ids = tokenizer(pseudo_targets).input_ids
+            S = len(ids)
+            targets = torch.tensor([ids if S else [0]] * num_negatives, dtype=torch.int32, device=device)
+            aug = log_p[:num_negatives].contiguous()
+            N, B = aug.shape[1], aug.shape[0]
+            ilen = torch.full((B,), N, dtype=torch.int32, device=device)
+            tlen = torch.full((B,), S, dtype=torch.int32, device=device)
+            _, _, g_lp = ops.ctc_loss(aug, targets, ilen, tlen, blank, reduction="mean", grad_scale=1.0)   # lib.py:351,434
+            g_logits = ops.log_softmax_bwd(aug, g_lp)
+            model.backward(g_logits, n_active=num_negatives)                                     # loss.backward(), lib.py:438
+            ops.clip_grad_norm(model.flat_grads, 10.0)                                           # lib.py:442
+            optimizer.step()
+            optimizer.zero_grad()
+            utterances[idx]['probs'] = log_p[-1].detach().cpu()
+    model.flat_params.copy_(original)                                                            # lib.py:459-460
+    return utterances
+
+
+def dynamic_eval_ctc_loss(args, model, spec, seq_len, overlap, tokenizer, processor, use_tqdm=True, optim=MADGRAD, num_negatives=1,
+                          lr_args={'lr': 1e-9}, return_device=False):
+    """reference wav2vec2/lib.py:41-235: waveform windows (`-seq 131072 -o 0`), online stitching of exp(log_p[-1])."""
+    device = model.device
+    spec = spec.to(device=device, dtype=torch.float32)                                           # [1, L] waveform
+    spec_n = spec.shape[-1]
+    downsampling_factor = 4
+    original = _snapshot(model)
+    optimizer = optim(model.parameters(), **lr_args)
+    blank = tokenizer.blank_id
+    decoder = GreedyCTCDecoder(tokenizer=tokenizer, blank_id=blank, device=device)
+    if seq_len > spec_n:
+        seq_len, overlap = spec_n, 0
+    assert overlap / downsampling_factor == overlap // downsampling_factor, 'Overlap must be a multiple of the downsampling factor'
+    V = tokenizer.vocab_size
+    acc = torch.zeros(spec_n // 4 + seq_len, V, device=device, dtype=torch.float32)
+    cnt = torch.zeros(spec_n // 4 + seq_len, device=device, dtype=torch.float32)
+    last_ulen, kill_next, training_data = None, False, {}
+    for i in range(0, spec_n, seq_len - overlap):                                               # lib.py:116-126
+        chunk = spec[:, i:i + seq_len]
+        u_len = chunk.shape[-1]
+        if kill_next:
+            break
+        elif last_ulen is not None and u_len < last_ulen:
+            kill_next = True
+        last_ulen = u_len
+        training_data[i] = chunk
+    outputs = {}
+    for epoch in range(args.__dict__.get('epochs', 1)):
+        outputs = {}
+        keys = list(training_data.keys())
+        keys = random.sample(keys, len(keys)) if args.__dict__.get('shuffle', False) else keys
+        for i in (tqdm(keys) if use_tqdm else keys):
+            chunk = training_data[i]
+            u_len = chunk.shape[-1]
+            audio = chunk.reshape(1, -1).repeat(num_negatives + 1, 1).contiguous()              # clean copies (see module doc)
+            input_values = normalize_waveform(audio)
+            with torch.enable_grad():
+                logits = model(input_values).logits
+            log_p = ops.log_softmax(logits)
+            ids = tokenizer(decoder(log_p[-1])).input_ids
+            S = len(ids)
+            targets = torch.tensor([ids if S else [0]] * num_negatives, dtype=torch.int32, device=device)
+            aug = log_p[:num_negatives].contiguous()
+            N, B = aug.shape[1], aug.shape[0]
+            ilen = torch.full((B,), N, dtype=torch.int32, device=device); tlen = torch.full((B,), S, dtype=torch.int32, device=device)
+            _, _, g_lp = ops.ctc_loss(aug, targets, ilen, tlen, blank, reduction="sum", grad_scale=1.0 / (N * B))
+            optimizer.zero_grad()
+            model.backward(ops.log_softmax_bwd(aug, g_lp), n_active=num_negatives)
+            optimizer.step()
+            ds_len = log_p.shape[1]
+            outputs[i] = (log_p[-1].detach(), ds_len, int(overlap / (u_len / ds_len)))
+    pos = end = 0
+    for i in sorted(outputs):
+        lp, ds_len, ov = outputs[i]
+        pos -= ov if i != 0 else 0
+        ops.stitch_accumulate(lp, acc, cnt, pos)
+        pos += ds_len
+        end = max(end, pos)
+    logits = ops.stitch_finalize(acc, cnt, end)
+    model.flat_params.copy_(original)
+    return logits if return_device else logits.cpu().numpy()
+
+
+dynamic_eval = dynamic_eval_ctc_loss
+dynamic_eval_su = dynamic_eval_ctc_loss_su

@@ -1,0 +1,357 @@
+"""Wav2Vec2ForCTC on MI355X: the model the reference's wav2vec2 path loads with
+`AutoModelForCTC.from_pretrained("facebook/wav2vec2-base-960h")` (reference wav2vec2/lib.py:20-23) and drives with
+`model(input_values).logits` (lib.py:163,413), with explicit forward / backward on the HIP kernels only.
+
+Architecture = HF `Wav2Vec2Config()` defaults (= base-960h: 7 strided Conv1d layers of 512 channels, GroupNorm on the
+first, feature projection LN + Linear(512 -> 768), grouped positional conv (k = 128, 16 groups, weight-normed) + GELU,
+12 post-LN transformer layers with 12 x 64 heads and GELU FFN 3072, lm_head 768 -> 32); `feat_extract_norm="group"`,
+`do_stable_layer_norm=False`, eval mode (no dropout, no SpecAugment masking) as in the reference loop.
+Parameter NAMES are HF's (state_dict interchange with transformers, which is the oracle in tests); the native HBM layout
+of conv kernels is [C_out][kernel][C_in] so each strided Conv1d is one implicit GEMM over overlapping rows of the
+channels-last activation (ops.conv1d), converted on load / save."""
+import math
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from .optim import ParamList
+
+DEFAULT_CONFIG = dict(
+    conv_dim=(512,) * 7, conv_stride=(5, 2, 2, 2, 2, 2, 2), conv_kernel=(10, 3, 3, 3, 3, 2, 2), hidden_size=768,
+    num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, num_conv_pos_embeddings=128,
+    num_conv_pos_embedding_groups=16, vocab_size=32, layer_norm_eps=1e-5,
+)
+
+
+def make_config(cfg=None):
+    out = dict(DEFAULT_CONFIG)
+    if cfg is not None:
+        src = cfg if isinstance(cfg, dict) else cfg.__dict__
+        for k in DEFAULT_CONFIG:
+            if k in src:
+                out[k] = tuple(src[k]) if isinstance(src[k], (list, tuple)) else src[k]
+        if not isinstance(cfg, dict):
+            assert getattr(cfg, "feat_extract_norm", "group") == "group" and not getattr(cfg, "do_stable_layer_norm", False) and \
+                not getattr(cfg, "conv_bias", False), "only the base (group-norm, post-LN, bias-free conv) variant is built"
+    return out
+
+
+def _conv_to_native(w):   # HF [Cout, Cin, k] -> native [Cout, k, Cin]
+    return w.permute(0, 2, 1).contiguous()
+
+
+def _conv_to_hf(w):       # native [Cout, k, Cin] -> HF [Cout, Cin, k]
+    return w.permute(0, 2, 1).contiguous()
+
+
+class Wav2Vec2ForCTC:
+    def __init__(self, config=None, device="cuda:0"):
+        self.cfg = make_config(config)
+        c = self.cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ops.DynError("Wav2Vec2ForCTC runs only on the HIP path (device must be cuda)")
+        H = c["hidden_size"]
+        assert H % 256 == 0 and c["conv_dim"][-1] % 256 == 0, "LayerNorm kernels need C % 256 == 0"
+        spec, self._conv = [("wav2vec2.masked_spec_embed", (H,), None)], {}
+        fe = "wav2vec2.feature_extractor.conv_layers."
+        cin = 1
+        for i, (co, k) in enumerate(zip(c["conv_dim"], c["conv_kernel"])):
+            spec.append((f"{fe}{i}.conv.weight", (co, k, cin), "conv"))
+            if i == 0:
+                spec += [(f"{fe}0.layer_norm.weight", (co,), None), (f"{fe}0.layer_norm.bias", (co,), None)]
+            cin = co
+        fp = "wav2vec2.feature_projection."
+        spec += [(fp + "layer_norm.weight", (cin,), None), (fp + "layer_norm.bias", (cin,), None),
+                 (fp + "projection.weight", (H, cin), None), (fp + "projection.bias", (H,), None)]
+        pc = "wav2vec2.encoder.pos_conv_embed.conv."
+        K, G = c["num_conv_pos_embeddings"], c["num_conv_pos_embedding_groups"]
+        spec += [(pc + "bias", (H,), None), (pc + "parametrizations.weight.original0", (K,), "g"),
+                 (pc + "parametrizations.weight.original1", (H, K, H // G), "conv")]
+        spec += [("wav2vec2.encoder.layer_norm.weight", (H,), None), ("wav2vec2.encoder.layer_norm.bias", (H,), None)]
+        for l in range(c["num_hidden_layers"]):
+            p = f"wav2vec2.encoder.layers.{l}."
+            for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                spec += [(p + f"attention.{n}.weight", (H, H), None), (p + f"attention.{n}.bias", (H,), None)]
+            spec += [(p + "layer_norm.weight", (H,), None), (p + "layer_norm.bias", (H,), None),
+                     (p + "feed_forward.intermediate_dense.weight", (c["intermediate_size"], H), None),
+                     (p + "feed_forward.intermediate_dense.bias", (c["intermediate_size"],), None),
+                     (p + "feed_forward.output_dense.weight", (H, c["intermediate_size"]), None),
+                     (p + "feed_forward.output_dense.bias", (H,), None),
+                     (p + "final_layer_norm.weight", (H,), None), (p + "final_layer_norm.bias", (H,), None)]
+        spec += [("lm_head.weight", (c["vocab_size"], H), None), ("lm_head.bias", (c["vocab_size"],), None)]
+        self.spec = spec
+        off, slots = 0, {}
+        for name, shape, _ in spec:
+            n = math.prod(shape)
+            slots[name] = (off, n, shape)
+            off += (n + 63) // 64 * 64
+        self.flat_params = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.flat_grads = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.P = {n: self.flat_params[o:o + k].view(s) for n, (o, k, s) in slots.items()}
+        self.G = {n: self.flat_grads[o:o + k].view(s) for n, (o, k, s) in slots.items()}
+        self._kind = {n: kind for n, _, kind in spec}
+        self.frozen = set()
+        self._ctx = None
+        self.config = SimpleNamespace(**c)
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def named_parameters(self):
+        return [(n, self.P[n]) for n, _, _ in self.spec]
+
+    def parameters(self):
+        pl = ParamList(self.P[n] for n, _, _ in self.spec)
+        pl.flat_params, pl.flat_grads = self.flat_params, self.flat_grads
+        return pl
+
+    def grads_hf(self):
+        """{name: gradient in HF layout} (tests)."""
+        return {n: self._to_hf(n, self.G[n]) for n, _, _ in self.spec}
+
+    def _to_hf(self, name, t):
+        kind = self._kind[name]
+        if kind == "conv":
+            return _conv_to_hf(t)
+        if kind == "g":
+            return t.reshape(1, 1, -1)
+        return t
+
+    def state_dict(self):
+        return {n: self._to_hf(n, p).detach().clone() for n, p in self.named_parameters()}
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [n for n, _, _ in self.spec if n not in sd]
+        if strict and missing:
+            raise KeyError(f"missing {missing[:4]}…")
+        for n, _, kind in self.spec:
+            if n not in sd:
+                continue
+            t = sd[n].to(torch.float32)
+            if kind == "conv":
+                t = _conv_to_native(t)
+            self.P[n].copy_(t.reshape(self.P[n].shape).to(self.device))
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=[k for k in sd if k not in self.P])
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def to(self, device):
+        return self
+
+    def modules(self):
+        return []
+
+    def zero_grad(self):
+        self.flat_grads.zero_()
+
+    # ------------------------------------------------------------------ forward
+    def __call__(self, input_values, **kw):
+        return self.forward(input_values)
+
+    def forward(self, input_values):
+        """input_values [B, L] float32 on the device (already zero-mean / unit-variance) -> SimpleNamespace(logits [B, T', V])."""
+        x = input_values
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
+            raise ops.DynError("input_values must be a float32 CUDA tensor [B, L]")
+        c, P = self.cfg, self.P
+        save = torch.is_grad_enabled()
+        ctx = {"conv": []} if save else None
+        B, L = x.shape
+        fe = "wav2vec2.feature_extractor.conv_layers."
+        a = x.contiguous().view(B, L, 1)
+        for i, (k, s) in enumerate(zip(c["conv_kernel"], c["conv_stride"])):
+            w = P[f"{fe}{i}.conv.weight"]
+            z = ops.conv1d(a, w.view(w.shape[0], -1), k, s)
+            if i == 0:
+                n0, mean, rstd = ops.colnorm(z, P[fe + "0.layer_norm.weight"], P[fe + "0.layer_norm.bias"], c["layer_norm_eps"])
+                act = ops.gelu(n0)
+                if save:
+                    ctx["conv"].append((a, z, (mean, rstd, n0)))
+            else:
+                act = ops.gelu(z)
+                if save:
+                    ctx["conv"].append((a, z, None))
+            a = act
+        T = a.shape[1]
+        fp = "wav2vec2.feature_projection."
+        n, mean, rstd = ops.layernorm(a, P[fp + "layer_norm.weight"], P[fp + "layer_norm.bias"], c["layer_norm_eps"])
+        h = ops.linear(n, P[fp + "projection.weight"], P[fp + "projection.bias"])
+        if save:
+            ctx["proj"] = (a, mean, rstd, n)
+        # positional conv embedding (grouped, weight-normed), GELU, residual, LayerNorm
+        pc = "wav2vec2.encoder.pos_conv_embed.conv."
+        H, K, G = c["hidden_size"], c["num_conv_pos_embeddings"], c["num_conv_pos_embedding_groups"]
+        cg, pad = H // G, K // 2
+        v, g = P[pc + "parametrizations.weight.original1"], P[pc + "parametrizations.weight.original0"]
+        w = ops.weight_norm(v, g)                                   # [H, K, cg]
+        xg = ops.group_pack(h, G, pad)                              # [B, G, T + 2 pad, cg]
+        Tp = T + 2 * pad
+        yg = torch.empty(B, G, T, cg, device=h.device, dtype=torch.float32)
+        ops.gemm(xg, w, yg, trans_b=True, M=T, N=cg, K=K * cg, lda=cg, ldb=K * cg, ldc=cg, nb1=B, nb2=G,
+                 sa=(G * Tp * cg, Tp * cg), sb=(0, cg * K * cg), sc=(G * T * cg, T * cg))
+        pre = ops.group_unpack(yg, P[pc + "bias"], T, H)
+        pos = ops.gelu(pre)
+        hs = h.clone() if save else h
+        ops.axpby(pos, hs, 1.0, 1.0)
+        h2, mean, rstd = ops.layernorm(hs, P["wav2vec2.encoder.layer_norm.weight"], P["wav2vec2.encoder.layer_norm.bias"], c["layer_norm_eps"])
+        if save:
+            ctx["pos"] = (xg, w, pre, hs, mean, rstd)
+            ctx["layers"] = []
+        h = h2
+        nh = c["num_attention_heads"]
+        D = H // nh
+        for l in range(c["num_hidden_layers"]):
+            p = f"wav2vec2.encoder.layers.{l}."
+            qkv = torch.empty(B, T, 3 * H, device=h.device, dtype=torch.float32)
+            for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                ops.gemm(h, P[p + f"attention.{nm}.weight"], qkv, trans_b=True, M=B * T, N=H, K=H, lda=H, ldb=H, ldc=3 * H,
+                         c_off=j * H, bias=P[p + f"attention.{nm}.bias"])
+            S = torch.empty(B, nh, T, T, device=h.device, dtype=torch.float32)
+            ops.gemm(qkv, qkv, S, trans_b=True, M=T, N=T, K=D, lda=3 * H, ldb=3 * H, ldc=T, nb1=B, nb2=nh,
+                     sa=(T * 3 * H, D), sb=(T * 3 * H, D), sc=(nh * T * T, T * T), b_off=H, alpha=D ** -0.5)
+            ops.softmax(S, out=S)
+            O = torch.empty(B, T, H, device=h.device, dtype=torch.float32)
+            ops.gemm(S, qkv, O, M=T, N=D, K=T, lda=T, ldb=3 * H, ldc=H, nb1=B, nb2=nh, sa=(nh * T * T, T * T),
+                     sb=(T * 3 * H, D), sc=(T * H, D), b_off=2 * H)
+            r1 = h.clone() if save else h
+            ops.linear(O, P[p + "attention.out_proj.weight"], P[p + "attention.out_proj.bias"], out=r1, beta=1.0)
+            h1, m1, s1 = ops.layernorm(r1, P[p + "layer_norm.weight"], P[p + "layer_norm.bias"], c["layer_norm_eps"])
+            u = ops.linear(h1, P[p + "feed_forward.intermediate_dense.weight"], P[p + "feed_forward.intermediate_dense.bias"])
+            ga = ops.gelu(u)
+            r2 = h1.clone() if save else h1
+            ops.linear(ga, P[p + "feed_forward.output_dense.weight"], P[p + "feed_forward.output_dense.bias"], out=r2, beta=1.0)
+            h2, m2, s2 = ops.layernorm(r2, P[p + "final_layer_norm.weight"], P[p + "final_layer_norm.bias"], c["layer_norm_eps"])
+            if save:
+                ctx["layers"].append((h, qkv, S, O, r1, m1, s1, h1, u, ga, r2, m2, s2))
+            h = h2
+        logits = ops.linear(h, P["lm_head.weight"], P["lm_head.bias"])
+        if save:
+            ctx["head"] = h
+            ctx["dims"] = (B, L, T)
+        self._ctx = ctx
+        return SimpleNamespace(logits=logits)
+
+    # ------------------------------------------------------------------ backward
+    def _lin_bwd(self, dy, x, wname, bname, need_dx=True):
+        ops.linear_wgrad(dy.contiguous(), x, self.G[wname], beta=1.0)
+        if bname is not None:
+            ops.colsum(dy, self.G[bname], beta=1.0)
+        return ops.linear_dgrad(dy, self.P[wname]) if need_dx else None
+
+    def backward(self, grad_logits, n_active=None):
+        """Accumulates dL/dparam into flat_grads given dL/dlogits [nb, T', V] for the first nb samples of the batch."""
+        ctx = self._ctx
+        if ctx is None:
+            raise ops.DynError("backward() without a grad-mode forward")
+        c, P, G = self.cfg, self.P, self.G
+        B, L, T = ctx["dims"]
+        nb = B if n_active is None else int(n_active)
+        assert grad_logits.shape[0] == nb
+
+        def cut(t):
+            if isinstance(t, tuple):
+                return tuple(cut(x) for x in t)
+            if t is None or nb == B:
+                return t
+            if t.dim() == 1:
+                return t[:nb * (t.shape[0] // B)]
+            return t[:nb]
+
+        H, nh = c["hidden_size"], c["num_attention_heads"]
+        D = H // nh
+        eps = c["layer_norm_eps"]
+        h_last = cut(ctx["head"])
+        dh = self._lin_bwd(grad_logits.contiguous(), h_last, "lm_head.weight", "lm_head.bias")
+        for l in reversed(range(c["num_hidden_layers"])):
+            p = f"wav2vec2.encoder.layers.{l}."
+            h, qkv, S, O, r1, m1, s1, h1, u, ga, r2, m2, s2 = cut(ctx["layers"][l])
+            dr2 = torch.empty_like(dh)
+            ops.layernorm_bwd(r2, P[p + "final_layer_norm.weight"], m2, s2, dh, dr2, G[p + "final_layer_norm.weight"],
+                              G[p + "final_layer_norm.bias"], dx_beta=0.0)
+            dga = self._lin_bwd(dr2, ga, p + "feed_forward.output_dense.weight", p + "feed_forward.output_dense.bias")
+            du = ops.gelu_bwd(u, dga, out=dga)
+            dh1 = self._lin_bwd(du, h1, p + "feed_forward.intermediate_dense.weight", p + "feed_forward.intermediate_dense.bias")
+            ops.axpby(dr2, dh1, 1.0, 1.0)                            # residual: h1 feeds both the FFN and r2
+            dr1 = torch.empty_like(dh1)
+            ops.layernorm_bwd(r1, P[p + "layer_norm.weight"], m1, s1, dh1, dr1, G[p + "layer_norm.weight"], G[p + "layer_norm.bias"],
+                              dx_beta=0.0)
+            dO = self._lin_bwd(dr1, O, p + "attention.out_proj.weight", p + "attention.out_proj.bias")
+            dqkv = torch.empty_like(qkv)
+            sS, sQ, sO = (nh * T * T, T * T), (T * 3 * H, D), (T * H, D)
+            ops.gemm(S, dO, dqkv, trans_a=True, M=T, N=D, K=T, lda=T, ldb=H, ldc=3 * H, nb1=nb, nb2=nh, sa=sS, sb=sO, sc=sQ, c_off=2 * H)
+            dP = torch.empty_like(S)
+            ops.gemm(dO, qkv, dP, trans_b=True, M=T, N=T, K=D, lda=H, ldb=3 * H, ldc=T, nb1=nb, nb2=nh, sa=sO, sb=sQ, sc=sS, b_off=2 * H)
+            ops.softmax_bwd(S, dP, out=dP, scale=1.0)
+            sc = D ** -0.5
+            ops.gemm(dP, qkv, dqkv, M=T, N=D, K=T, lda=T, ldb=3 * H, ldc=3 * H, nb1=nb, nb2=nh, sa=sS, sb=sQ, sc=sQ, b_off=H, c_off=0, alpha=sc)
+            ops.gemm(dP, qkv, dqkv, trans_a=True, M=T, N=D, K=T, lda=T, ldb=3 * H, ldc=3 * H, nb1=nb, nb2=nh, sa=sS, sb=sQ, sc=sQ,
+                     b_off=0, c_off=H, alpha=sc)
+            dh_in = dr1                                              # residual path of the attention block
+            M = nb * T
+            for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                # dW += dqkv_j^T h ; db += colsum ; dh += dqkv_j W      (dqkv_j is a strided [M, H] slice, lda = 3H)
+                ops.gemm(dqkv, h, G[p + f"attention.{nm}.weight"], trans_a=True, M=H, N=H, K=M, lda=3 * H, ldb=H, ldc=H, a_off=j * H, beta=1.0)
+                dj = dqkv.view(M, 3, H)[:, j, :].contiguous()
+                ops.colsum(dj, G[p + f"attention.{nm}.bias"], beta=1.0)
+                ops.gemm(dqkv, P[p + f"attention.{nm}.weight"], dh_in, M=M, N=H, K=H, lda=3 * H, ldb=H, ldc=H, a_off=j * H, beta=1.0)
+            dh = dh_in
+            ctx["layers"][l] = None
+        # encoder LayerNorm, positional conv
+        w = ctx["pos"][1]                                            # the normalised weight is not batch-indexed
+        xg, _, pre, hs, mean, rstd = cut(ctx["pos"])
+        pc = "wav2vec2.encoder.pos_conv_embed.conv."
+        K, Gn = c["num_conv_pos_embeddings"], c["num_conv_pos_embedding_groups"]
+        cg, pad = H // Gn, K // 2
+        Tp = T + 2 * pad
+        dhs = torch.empty_like(dh)
+        ops.layernorm_bwd(hs, P["wav2vec2.encoder.layer_norm.weight"], mean, rstd, dh, dhs, G["wav2vec2.encoder.layer_norm.weight"],
+                          G["wav2vec2.encoder.layer_norm.bias"], dx_beta=0.0)
+        dpre = ops.gelu_bwd(pre, dhs)
+        ops.colsum(dpre, G[pc + "bias"], beta=1.0)
+        dyg = ops.group_pack_grad(dpre, Gn, T)                       # [nb, G, T, cg]
+        dw = torch.zeros_like(w)
+        for b in range(nb):                                          # dw[g] += dyg[b, g]^T rows(xg[b, g])
+            ops.gemm(dyg, xg, dw, trans_a=True, M=cg, N=K * cg, K=T, lda=cg, ldb=cg, ldc=K * cg, nb1=1, nb2=Gn,
+                     sa=(0, T * cg), sb=(0, Tp * cg), sc=(0, cg * K * cg), a_off=b * Gn * T * cg, b_off=b * Gn * Tp * cg, beta=1.0)
+        v, g = P[pc + "parametrizations.weight.original1"], P[pc + "parametrizations.weight.original0"]
+        ops.weight_norm_bwd(v, g, dw, G[pc + "parametrizations.weight.original1"], G[pc + "parametrizations.weight.original0"], beta=1.0)
+        dA = torch.empty(nb, Gn, T, K * cg, device=dh.device, dtype=torch.float32)
+        ops.gemm(dyg, w, dA, M=T, N=K * cg, K=cg, lda=cg, ldb=K * cg, ldc=K * cg, nb1=nb, nb2=Gn, sa=(Gn * T * cg, T * cg),
+                 sb=(0, cg * K * cg), sc=(Gn * T * K * cg, T * K * cg))
+        dxg = torch.empty(nb * Gn, Tp, cg, device=dh.device, dtype=torch.float32)
+        from ._lib import check, load
+        check(load().dyn_col2im_1d(dA.data_ptr(), dxg.data_ptr(), nb * Gn, Tp, T, cg, K, 1, torch.cuda.current_stream().cuda_stream),
+              "dyn_col2im_1d")
+        ops.group_unpack_grad(dxg.view(nb, Gn, Tp, cg), dhs, pad, beta=1.0)   # dh (pre-pos) = dhs (residual) + pos-conv path
+        # feature projection
+        a, mean, rstd, n = cut(ctx["proj"])
+        fp = "wav2vec2.feature_projection."
+        dn = self._lin_bwd(dhs, n, fp + "projection.weight", fp + "projection.bias")
+        da = torch.empty_like(dn)
+        ops.layernorm_bwd(a, P[fp + "layer_norm.weight"], mean, rstd, dn, da, G[fp + "layer_norm.weight"], G[fp + "layer_norm.bias"], dx_beta=0.0)
+        # conv feature extractor
+        fe = "wav2vec2.feature_extractor.conv_layers."
+        for i in reversed(range(len(c["conv_kernel"]))):
+            k, s = c["conv_kernel"][i], c["conv_stride"][i]
+            a_in, z, norm = cut(ctx["conv"][i])
+            wname = f"{fe}{i}.conv.weight"
+            wmat = P[wname].view(P[wname].shape[0], -1)
+            if i == 0:
+                mean, rstd, n0 = norm
+                dn0 = ops.gelu_bwd(n0, da)
+                dz = ops.colnorm_bwd(z, P[fe + "0.layer_norm.weight"], mean, rstd, dn0, G[fe + "0.layer_norm.weight"], G[fe + "0.layer_norm.bias"])
+            else:
+                dz = ops.gelu_bwd(z, da)
+            ops.conv1d_wgrad(a_in, dz, G[wname].view(wmat.shape), k, s, beta=1.0)
+            if i > 0:
+                da = ops.conv1d_dgrad(dz, wmat, a_in.shape[1], a_in.shape[2], k, s)
+            ctx["conv"][i] = None
+        self._ctx = None
+        for name in self.frozen:
+            for n, _, _ in self.spec:
+                if n.startswith(name):
+                    self.G[n].zero_()

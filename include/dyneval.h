@@ -215,6 +215,39 @@ int dyn_stitch_accumulate(const float* log_probs, int64_t ld, float* acc, float*
 int dyn_stitch_finalize(const float* acc, const float* count, float* out, int64_t rows, int64_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * wav2vec2 encoder pieces (reference wav2vec2/lib.py:20-23 loads HF Wav2Vec2ForCTC; forward at :163,413, backward at
+ * :194,437).  The strided Conv1d feature extractor and the grouped positional conv are dyn_gemm_f32 calls over
+ * OVERLAPPING rows of channels-last activations (lda = stride * C_in < K = kernel * C_in); these are the passes around
+ * them.  Layouts: activations [B, T, C]; conv weights [C_out][kernel][C_in]; positional conv v / w [G * C_out/G][kernel][C/G].
+ *   dyn_gelu_*          exact erf GELU
+ *   dyn_colnorm_*       GroupNorm(groups == channels): per-(batch, channel) normalisation over time, biased variance
+ *   dyn_col2im_1d       input gradient of a strided Conv1d from the dense [B, T_out, kernel*C] gradient of its rows
+ *   dyn_group_pack ...  [B, T, C] <-> group-major zero-padded [B, G, T + 2 pad, C/G] (and the gradient counterparts)
+ *   dyn_weight_norm_*   w = g[tap] * v / ||v[:, tap, :]||_F  (torch weight_norm with dim = 2) and its backward
+ * ------------------------------------------------------------------------------------------------ */
+int dyn_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+int dyn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+int64_t dyn_colnorm_workspace_bytes(int64_t B, int64_t T, int64_t C);
+int dyn_colnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t B,
+                    int64_t T, int64_t C, float eps, void* workspace, int64_t workspace_bytes, void* stream);
+int dyn_colnorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
+                    float* dgamma, float* dbeta, float wgrad_beta, int64_t B, int64_t T, int64_t C, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+int dyn_col2im_1d(const float* dA, float* dx, int64_t B, int64_t Tin, int64_t Tout, int64_t C, int64_t kw, int64_t stride,
+                  void* stream);
+int dyn_group_pack(const float* x, float* xg, int64_t B, int64_t T, int64_t C, int64_t G, int64_t pad, void* stream);
+int dyn_group_unpack(const float* yg, float* y, const float* bias, int64_t B, int64_t T, int64_t Tg, int64_t C, int64_t G,
+                     void* stream);
+int dyn_group_pack_grad(const float* dy, float* dyg, int64_t B, int64_t T, int64_t Tg, int64_t C, int64_t G, void* stream);
+int dyn_group_unpack_grad(const float* dxg, float* dx, int64_t B, int64_t T, int64_t C, int64_t G, int64_t pad, float beta,
+                          void* stream);
+int64_t dyn_weight_norm_workspace_bytes(int64_t rows, int64_t kw);
+int dyn_weight_norm_fwd(const float* v, const float* g, float* w, int64_t rows, int64_t kw, int64_t cg, void* workspace,
+                        int64_t workspace_bytes, void* stream);
+int dyn_weight_norm_bwd(const float* v, const float* g, const float* dw, float* dv, float* dg, float beta, int64_t rows,
+                        int64_t kw, int64_t cg, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Soft-DTW — replaces the reference's Numba CUDA kernels compute_softdtw_cuda / compute_softdtw_backward_cuda
  * (reference wav2vec2/soft_dtw_cuda.py:33-111), their autograd wrapper (:114-175) and _euclidean_dist_func (:319-329).
  *   dyn_sqdist       D[b,i,j] = sum_k (x[b,i,k] - y[b,j,k])^2            x [B,N,d], y [B,M,d] -> D [B,N,M]
