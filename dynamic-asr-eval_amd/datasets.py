@@ -78,3 +78,11 @@ def get_text_and_audio_synthetic_wave(split, durations_s=None, seed=4321):
 
 
 datasets_functions['synthetic_wave'] = get_text_and_audio_synthetic_wave
+
+
+def get_text_and_audio_synthetic_small(split, seed=99):
+    """A few short recordings (tests / harness smoke runs)."""
+    return get_text_and_audio_synthetic(split, durations_s=[14.0, 9.0, 11.5] if split == 'test' else [8.0, 6.0], seed=seed)
+
+
+datasets_functions['synthetic_small'] = get_text_and_audio_synthetic_small
