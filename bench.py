@@ -110,7 +110,7 @@ def main():
 
     rank, local_rank, world = ddist.init()
     assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", ddist.local_device_index(local_rank))
     torch.cuda.set_device(dev)
     model = SCConformerXL(vocab_size=a.vocab, device=dev)
     init_synthetic(model, seed=0, blank_bias=0.0)

@@ -14,16 +14,23 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+def local_device_index(local_rank):
+    """GPU of this rank: LOCAL_RANK, folded onto the visible devices when ranks outnumber them (rehearsal only)."""
+    n = torch.cuda.device_count()
+    return local_rank % n if n > 0 else 0
+
+
 def init(backend=None):
     """Initialise the default process group from the torchrun environment; returns (rank, local_rank, world)."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # DYN_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks
+            backend = os.environ.get("DYN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_device_index(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 

@@ -22,7 +22,7 @@ from .run_dynamic_eval_full import load_model_and_tokenizer
 def main(args):
     assert args.split in ['test', 'dev'], f'Split must be either test or dev (got {args.split})'
     rank, local_rank, world = ddist.init()
-    device = torch.device('cuda', local_rank)
+    device = torch.device('cuda', ddist.local_device_index(local_rank))
     torch.cuda.set_device(device)
     model, tokenizer = load_model_and_tokenizer(args, device)
     decoder = GreedyCTCDecoder(tokenizer=tokenizer, blank_id=model.decoder.num_classes - 1, device=device)
