@@ -28,6 +28,7 @@ class GemmDesc(ctypes.Structure):
         ("split_k", ctypes.c_int32),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
         ("tile_m", ctypes.c_int32), ("tile_n", ctypes.c_int32), ("tail_slices", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+        ("C_in", ctypes.c_void_p),
     ]
 
 

@@ -114,6 +114,25 @@ __global__ void colsum_partial_kernel(const float* __restrict__ x, float* __rest
     if (rl == 0 && col < C) partial[(int64_t)blockIdx.y * C + col] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
+// Column sums in ONE launch for the common small case (bias gradients of a 2048..8192-row activation): 1024 threads =
+// 32 columns x 32 row-lanes, one 128-B segment per row per wave half; lanes are combined through LDS in lane order.
+__global__ __launch_bounds__(1024) void colsum_single_kernel(const float* __restrict__ x, float* out, int64_t rows, int C, float beta) {
+    __shared__ float red[32][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cl;
+    float s = 0.f;
+    if (col < C)
+        for (int64_t r = rl; r < rows; r += 32) s += x[r * C + col];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && col < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += red[k][cl];
+        out[col] = (beta != 0.f ? beta * out[col] : 0.f) + t;
+    }
+}
+
 // out[n] = beta * out[n] + sum_p partial[p, n]   (p in increasing order)
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, float* out, int64_t P, int64_t n, float beta) {
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
@@ -218,6 +237,10 @@ extern "C" int dyn_colsum(const float* x, float* out, int64_t rows, int64_t C, f
                 "dyn_colsum: workspace too small");
     const int64_t rpc = dyn::cdiv(rows > 0 ? rows : 1, chunks);
     hipStream_t st = (hipStream_t)stream;
+    if (rows <= 8192 && C >= 256) {  // enough column strips to occupy the chip: one launch instead of two
+        hipLaunchKernelGGL(colsum_single_kernel, dim3((unsigned)dyn::cdiv(C, 32)), dim3(1024), 0, st, x, out, rows, (int)C, beta);
+        return dyn::check_launch("dyn_colsum");
+    }
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)dyn::cdiv(C, 64), (unsigned)chunks), dim3(256), 0, st, x,
                        (float*)workspace, rows, (int)C, rpc);
     dyn::launch_reduce_partials((const float*)workspace, out, chunks, C, beta, st);

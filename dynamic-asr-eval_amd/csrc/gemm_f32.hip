@@ -37,6 +37,7 @@ struct KParams {
     const float* A; int64_t lda, sa1, sa2;
     const float* B; int64_t ldb, sb1, sb2;
     float* C; int64_t ldc, sc1, sc2;
+    int64_t cin_delta;  // C_in - C in elements (0 = accumulate in place): beta reads the residual from another buffer
     const float* bias;
     float alpha, beta;
     int64_t nb2;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         float* q2 = cp + (int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc;
-                        *q2 = p.alpha * acc[a][b][e] + p.beta * *q2 + bv;
+                        *q2 = p.alpha * acc[a][b][e] + p.beta * q2[p.cin_delta] + bv;
                     }
                 } else {
 #pragma unroll
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
                     const int64_t row = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (row < p.M && col < p.N) {
                         float v = p.alpha * acc[a][b][e];
-                        if (p.beta != 0.f) v += p.beta * C[row * p.ldc + col];
+                        if (p.beta != 0.f) v += p.beta * C[row * p.ldc + col + p.cin_delta];
                         C[row * p.ldc + col] = v + bv;
                     }
                 }
@@ -336,7 +337,7 @@ __global__ void splitk_reduce_kernel(const KParams p) {
         const int64_t z1 = zb / p.nb2, z2 = zb % p.nb2;
         float* C = p.C + z1 * p.sc1 + z2 * p.sc2 + row * p.ldc + col;
         float v = p.alpha * s;
-        if (p.beta != 0.f) v += p.beta * *C;
+        if (p.beta != 0.f) v += p.beta * C[p.cin_delta];
         if (p.bias) v += p.bias[col];
         *C = v;
     }
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(const KParams p, int B
             const int64_t col = col0 + j;
             if (col < p.N) {
                 float o = p.alpha * v[j];
-                if (p.beta != 0.f) o += p.beta * C[col];
+                if (p.beta != 0.f) o += p.beta * C[col + p.cin_delta];
                 if (p.bias) o += p.bias[col];
                 C[col] = o;
             }
@@ -519,6 +520,7 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
     kp.B = d->B; kp.ldb = d->ldb; kp.sb1 = d->sb1; kp.sb2 = d->sb2;
     kp.C = d->C; kp.ldc = d->ldc; kp.sc1 = d->sc1; kp.sc2 = d->sc2;
     kp.bias = d->bias; kp.alpha = d->alpha; kp.beta = d->beta;
+    kp.cin_delta = d->C_in ? (int64_t)(d->C_in - d->C) : 0;
     kp.nb2 = d->nb2; kp.splits = pl.splits; kp.kchunk = pl.kchunk;
     kp.ws = (float*)d->workspace; kp.nbatch = batch;
     const int64_t tiles_m = dyn::cdiv(d->M, pl.bm), tiles_n = dyn::cdiv(d->N, pl.bn);

@@ -175,8 +175,11 @@ int launch_bwd(const float* x, const float* gamma, const float* mean, const floa
         case 8: hipLaunchKernelGGL((norm_bwd_kernel<8, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows); break;
         default: dyn::set_error("norm: unsupported C=%lld", (long long)C); return DYN_E_UNSUPPORTED;
     }
-    if (dgamma) dyn::launch_reduce_partials(pg, dgamma, (int64_t)nb, C, wbeta, st);
-    if (!RMS && dbeta) dyn::launch_reduce_partials(pb, dbeta, (int64_t)nb, C, wbeta, st);
+    if (!RMS && dgamma && dbeta) dyn::launch_reduce_partials_pair(pg, dgamma, pb, dbeta, (int64_t)nb, C, wbeta, st);
+    else {
+        if (dgamma) dyn::launch_reduce_partials(pg, dgamma, (int64_t)nb, C, wbeta, st);
+        if (!RMS && dbeta) dyn::launch_reduce_partials(pb, dbeta, (int64_t)nb, C, wbeta, st);
+    }
     return dyn::check_launch("dyn_norm_bwd");
 }
 

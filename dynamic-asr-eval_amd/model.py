@@ -121,6 +121,7 @@ class SCConformerXL:
         self._rot = {}
         self._ctx = None
         self._skip_wgrad = False
+        self.fused_convmod = True   # GLU + dwconv + norm + SiLU in one kernel (csrc/convmod.hip)
         self.training = False
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -239,8 +240,10 @@ class SCConformerXL:
                 n, mean, rstd = ops.layernorm(h, P["decoder.norm.weight"], P["decoder.norm.bias"], cfg["norm_eps"])
                 z = ops.linear(n, P["decoder.ff.weight"], P["decoder.ff.bias"])
                 ops.softmax(z, out=z)
-                h2 = h.clone() if save else h
-                ops.linear(z, P["decoder.reproj.weight"], P["decoder.reproj.bias"], out=h2, beta=1.0)
+                if save:
+                    h2 = ops.linear(z, P["decoder.reproj.weight"], P["decoder.reproj.bias"], beta=1.0, residual=h)
+                else:
+                    h2 = ops.linear(z, P["decoder.reproj.weight"], P["decoder.reproj.bias"], out=h, beta=1.0)
                 if save:
                     ctx["sc"].append((h, mean, rstd, n, z))
                 h = h2
@@ -258,8 +261,10 @@ class SCConformerXL:
         n, mean, rstd = ops.layernorm(h, P[p + ".norm.weight"], P[p + ".norm.bias"], eps)
         u = ops.linear(n, P[p + ".w1.weight"])
         a = ops.silu(u)
-        out = h.clone() if lc is not None else h
-        ops.linear(a, P[p + ".w2.weight"], out=out, alpha=0.5, beta=1.0)
+        if lc is not None:   # keep h for the backward: the GEMM reads the residual from h and writes a new buffer
+            out = ops.linear(a, P[p + ".w2.weight"], alpha=0.5, beta=1.0, residual=h)
+        else:
+            out = ops.linear(a, P[p + ".w2.weight"], out=h, alpha=0.5, beta=1.0)
         if lc is not None:
             lc[key] = (h, mean, rstd, n, u, a)
         return out
@@ -280,8 +285,10 @@ class SCConformerXL:
         O = torch.empty(B, T, HD, device=h.device, dtype=torch.float32)
         ops.gemm(S, qkv, O, M=T, N=D, K=T, lda=T, ldb=3 * HD, ldc=HD, nb1=B, nb2=H, sa=(H * T * T, T * T),
                  sb=(T * 3 * HD, D), sc=(T * HD, D), b_off=2 * HD)
-        out = h.clone() if lc is not None else h
-        ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], out=out, beta=1.0)
+        if lc is not None:
+            out = ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], beta=1.0, residual=h)
+        else:
+            out = ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], out=h, beta=1.0)
         if lc is not None:
             lc["attn"] = (h, mean, rstd, n, qkv, S, O)
         return out
@@ -301,12 +308,20 @@ class SCConformerXL:
         cfg, P = self.config, self.P
         n, mean, rstd = ops.layernorm(h, P[p + ".norm.weight"], P[p + ".norm.bias"], cfg["norm_eps"])
         u = ops.linear(n, P[p + ".pw1.weight"], P[p + ".pw1.bias"])
-        g = ops.glu(u)
-        c = ops.dwconv1d(g, P[p + ".dw.weight"], P[p + ".dw.bias"])
-        nn_, stats = self._cnorm_fwd(c, p)
-        s = ops.silu(nn_)
-        out = h.clone() if lc is not None else h
-        ops.linear(s, P[p + ".pw2.weight"], P[p + ".pw2.bias"], out=out, beta=1.0)
+        if cfg["conv_kernel_size"] == 9 and cfg["d_model"] <= 1024 and self.fused_convmod:
+            ln = cfg["conv_norm"] == "layer_norm"
+            s, g, c, nn_, cmean, crstd = ops.convmod_fwd(u, P[p + ".dw.weight"], P[p + ".dw.bias"], P[p + ".cnorm.weight"],
+                                                         P[p + ".cnorm.bias"] if ln else None, ln, cfg["norm_eps"], lc is not None)
+            stats = (cmean, crstd)
+        else:
+            g = ops.glu(u)
+            c = ops.dwconv1d(g, P[p + ".dw.weight"], P[p + ".dw.bias"])
+            nn_, stats = self._cnorm_fwd(c, p)
+            s = ops.silu(nn_)
+        if lc is not None:
+            out = ops.linear(s, P[p + ".pw2.weight"], P[p + ".pw2.bias"], beta=1.0, residual=h)
+        else:
+            out = ops.linear(s, P[p + ".pw2.weight"], P[p + ".pw2.bias"], out=h, beta=1.0)
         if lc is not None:
             lc["conv"] = (h, mean, rstd, n, u, g, c, stats, nn_, s)
         return out

@@ -66,7 +66,7 @@ def workspace(device=None):
 
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
-         nb1=1, nb2=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, split_k=0, force=None):
+         nb1=1, nb2=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, split_k=0, force=None, c_in=None):
     """Raw strided batched GEMM (see dyn_gemm_desc). Offsets are in elements from each tensor's data_ptr.
     `force=(tile_m, tile_n, tail_slices)` pins the kernel configuration (autotuner / tests)."""
     _chk(a, "gemm.A"); _chk(b, "gemm.B"); _chk(c, "gemm.C")
@@ -80,6 +80,7 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha
     d.B, d.ldb, d.sb1, d.sb2 = b.data_ptr() + 4 * b_off, ldb, sb[0], sb[1]
     d.C, d.ldc, d.sc1, d.sc2 = c.data_ptr() + 4 * c_off, ldc, sc[0], sc[1]
     d.bias = bias.data_ptr() if bias is not None else None
+    d.C_in = (c_in.data_ptr() + 4 * c_off) if c_in is not None else None   # residual source (same addressing as C)
     d.nb1, d.nb2 = nb1, nb2
     d.split_k = split_k
     ws = workspace(c.device)
@@ -121,17 +122,17 @@ def gemm_profile_stop():
             "sampled_flops": fl, "sampled_ms": ms}
 
 
-def linear(x, w, bias=None, out=None, alpha=1.0, beta=0.0):
-    """out[M, N] = alpha * x[M, K] @ w[N, K]^T + beta * out + bias   (torch.nn.Linear weight layout)."""
+def linear(x, w, bias=None, out=None, alpha=1.0, beta=0.0, residual=None):
+    """out[M, N] = alpha * x[M, K] @ w[N, K]^T + beta * (residual if given else out) + bias   (torch.nn.Linear layout)."""
     _cc(x, "linear.x"); _cc(w, "linear.w")
     K = x.shape[-1]
     M = x.numel() // K
     N = w.shape[0]
     assert w.shape[1] == K, (w.shape, K)
     if out is None:
-        assert beta == 0.0
+        assert beta == 0.0 or residual is not None
         out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=F32)
-    return gemm(x, w, out, trans_b=True, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, alpha=alpha, beta=beta)
+    return gemm(x, w, out, trans_b=True, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, alpha=alpha, beta=beta, c_in=residual)
 
 
 def linear_dgrad(dy, w, out=None, alpha=1.0, beta=0.0):
@@ -361,6 +362,24 @@ def dwconv1d_wgrad(x, dy, dw, dbias, beta=1.0):
     ws = workspace(x.device)
     check(_L().dyn_dwconv1d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _opt(dbias, "dbias"), beta, B, T, C,
                                   dw.shape[1], ws.data_ptr(), ws.numel(), _stream()), "dyn_dwconv1d_wgrad")
+
+
+def convmod_fwd(u, w, bias, gamma, beta, layernorm, eps, save):
+    """Fused GLU -> dwconv(k=9) -> norm -> SiLU.  u [B, T, 2C] -> s [B, T, C]; with `save` also (g, c, nn, mean, rstd)."""
+    _cc(u, "convmod.u"); _cc(w, "convmod.w")
+    B, T, C2 = u.shape
+    C = C2 // 2
+    dev = u.device
+    s = torch.empty(B, T, C, device=dev, dtype=F32)
+    g = c = nn = mean = rstd = None
+    if save:
+        g, c, nn = (torch.empty(B, T, C, device=dev, dtype=F32) for _ in range(3))
+        rstd = torch.empty(B * T, device=dev, dtype=F32)
+        mean = torch.empty(B * T, device=dev, dtype=F32) if layernorm else None
+    check(_L().dyn_convmod_fwd(u.data_ptr(), w.data_ptr(), _opt(bias, "bias"), gamma.data_ptr(), _opt(beta, "beta"), s.data_ptr(),
+                               _opt(g, "g"), _opt(c, "c"), _opt(nn, "nn"), _opt(mean, "mean"), _opt(rstd, "rstd"), B, T, C, w.shape[1],
+                               int(layernorm), eps, _stream()), "dyn_convmod_fwd")
+    return s, g, c, nn, mean, rstd
 
 
 def out_len(n):

@@ -57,6 +57,9 @@ typedef struct {
      * scripts/tune_gemm.py to time candidates: tile 64|128 x 64|128, tail_slices = K-slices of the last partial
      * round of workgroups (1 = off) */
     int32_t tile_m, tile_n, tail_slices, reserved_;
+    /* optional residual source: C = alpha*A@B + beta*C_in (+ bias), C_in addressed exactly like C (same ldc / batch
+     * strides); NULL = accumulate in place.  Lets `x_new = x + f(x)` keep x intact for the backward without a copy. */
+    const float* C_in;
 } dyn_gemm_desc;
 
 int64_t dyn_gemm_f32_workspace_bytes(const dyn_gemm_desc* d);
@@ -118,6 +121,13 @@ int dyn_dwconv1d_dgrad(const float* dy, const float* w, float* dx, int64_t B, in
 int64_t dyn_dwconv1d_wgrad_workspace_bytes(int64_t B, int64_t T, int64_t C, int64_t KW);
 int dyn_dwconv1d_wgrad(const float* x, const float* dy, float* dw, float* dbias, float beta, int64_t B, int64_t T, int64_t C,
                        int64_t KW, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Fused conformer conv-module core (GLU -> depthwise k=9 -> RMSNorm | LayerNorm over channels -> SiLU), one pass:
+ *   u [B, T, 2C] -> s [B, T, C];  optional outputs for the backward: g (GLU), c (conv), nn (norm output), mean, rstd [B*T].
+ * C in {256, 512, 768, 1024}, kernel width 9. */
+int dyn_convmod_fwd(const float* u, const float* w, const float* bias, const float* gamma, const float* beta, float* s,
+                    float* g_out, float* c_out, float* nn_out, float* mean_out, float* rstd_out, int64_t B, int64_t T, int64_t C,
+                    int64_t KWIDTH, int32_t layernorm, float eps, void* stream);
 
 /* dw_striding x8 subsampling (`subsampling: dw_striding`, `subsampling_conv_channels: 256`, `subsampling_act: silu`,
  * yaml:10-13), channels-last.  Output sizes: To = (T-1)/2+1, Fo = (F-1)/2+1 (3x3, stride 2, pad 1).

@@ -195,3 +195,24 @@ def test_entropy_augmentation_matches_autograd(cuda):
     rel = (delta - delta_ref).abs().max().item() / delta_ref.abs().max().item()
     assert rel < 2e-3, rel
     assert torch.equal(lib.entropy_augmentation(spec.to(cuda), hip, enabled=False).cpu(), spec)
+
+
+@pytest.mark.parametrize("conv_norm", ["rms_norm", "layer_norm"])
+def test_fused_convmod_matches_unfused(cuda, conv_norm):
+    """csrc/convmod.hip (GLU + dwconv k=9 + norm + SiLU in one pass) vs the four separate kernels, forward and backward."""
+    cfg = dict(SMALL, conv_norm=conv_norm)
+    ref, hip = _pair(cuda, cfg, vocab=128, seed=23)
+    x = torch.randn(2, 80, 333, generator=torch.Generator().manual_seed(8)).to(cuda)
+    outs, grads = [], []
+    for fused in (True, False):
+        hip.fused_convmod = fused
+        out = hip(audio_signal=x)['final_posteriors']
+        gp = torch.randn(out.shape, generator=torch.Generator().manual_seed(9)).to(cuda) / out.numel()
+        hip.zero_grad(); hip.backward(gp)
+        outs.append(out.clone()); grads.append(hip.flat_grads.clone())
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-5
+    assert (grads[0] - grads[1]).abs().max().item() / grads[1].abs().max().item() < 1e-4
+    with torch.no_grad():
+        hip.fused_convmod = True
+        a = hip(audio_signal=x)['final_posteriors']
+    assert (a - outs[0]).abs().max().item() < 1e-6
