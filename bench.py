@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--blank_bias", type=float, default=-1.0, help="<0: calibrate for a speech-like token rate")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_windows", type=int, default=1)
+    ap.add_argument("--graphs", type=int, default=1, help="hipGraph replay of the per-window launch sequences")
+    ap.add_argument("--chains", type=int, default=2, help="independent recordings in flight per GPU (own stream + model replica)")
     return ap.parse_args()
 
 
@@ -63,7 +65,8 @@ def make_args(a):
     ns = argparse.Namespace()
     ns.config = {'model': {'subsampling_factor': 8}, 'audio_chunking': {'size': 16384, 'overlap': 0}, 'training': {'max_seq_len': 0}}
     ns.__dict__.update(dict(optim_lr=a.lr, epochs=1, shuffle=False, online=bool(a.online), quiet=True,
-                            spec_augment_n_freq_masks=6, spec_augment_freq_mask_param=34, spec_augment_n_time_masks=0))
+                            spec_augment_n_freq_masks=6, spec_augment_freq_mask_param=34, spec_augment_n_time_masks=0,
+                            use_graphs=bool(a.graphs)))
     return ns
 
 
@@ -112,21 +115,27 @@ def main():
     assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", ddist.local_device_index(local_rank))
     torch.cuda.set_device(dev)
-    model = SCConformerXL(vocab_size=a.vocab, device=dev)
-    init_synthetic(model, seed=0, blank_bias=0.0)
+    n_chains = max(1, min(a.chains, a.steps))
+    models = []
+    for _ in range(n_chains):
+        m = SCConformerXL(vocab_size=a.vocab, device=dev)
+        init_synthetic(m, seed=0, blank_bias=0.0)
+        models.append(m)
+    model = models[0]
     tok = SyntheticTokenizer(a.vocab)
-    decoder = GreedyCTCDecoder(tok, blank_id=a.vocab, device=dev)
     args = make_args(a)
     n_frames = int(a.seconds * 100)
     torch.manual_seed(1234 + rank)
 
     def one_step(step_idx):
-        spec = synthetic_spec(n_frames, seed=1234 + 1000 * rank + step_idx).to(dev)  # resident in HBM before timing
-        return spec
+        return synthetic_spec(n_frames, seed=1234 + 1000 * rank + step_idx).to(dev)  # resident in HBM before timing
 
-    def run(spec):
-        logits = lib.dynamic_eval(args, model, spec, a.seq_len, a.overlap, tok, use_tqdm=False, return_device=True)
-        return decoder.ids(logits)
+    decoder = GreedyCTCDecoder(tok, blank_id=a.vocab, device=dev)
+
+    def run_many(spec_list):
+        """`n_chains` recordings in flight: one stream + one model replica each, advanced round-robin by one host thread."""
+        outs = lib.dynamic_eval_many(args, models, spec_list, a.seq_len, a.overlap, tok, use_tqdm=False, return_device=True)
+        return [decoder.ids(o) for o in outs]
 
     specs = [one_step(i) for i in range(a.warmup + a.steps)]
     if a.blank_bias < 0:  # shape the seeded model so pseudo-labels have a speech-like token rate (outside the timed region)
@@ -134,19 +143,22 @@ def main():
         a.blank_bias = calibrate_blank_bias(model, specs[0][:, :, :a.seq_len].contiguous())
     else:
         model.P["decoder.ff.bias"][-1] += a.blank_bias
-    for i in range(a.warmup):
-        run(specs[i])
+    for m in models[1:]:                       # every chain starts from the same weights
+        m.flat_params.copy_(model.flat_params)
+    if a.warmup:
+        run_many(specs[:a.warmup] * n_chains)                                  # every chain (stream, workspace) is warmed
     ddist.barrier()
     torch.cuda.synchronize(dev)
-    ops.gemm_profile_start(every=16)
+    ops.gemm_profile_start(every=4, window_every=16 if a.graphs else 0)  # graph replays cannot be timed per launch: every 16th
+                                                                         # window step of the timed region runs eagerly and is sampled
     t0 = time.perf_counter()
-    hyps = []
-    for i in range(a.warmup, a.warmup + a.steps):
-        hyps.append(run(specs[i]))
+    hyps = run_many(specs[a.warmup:a.warmup + a.steps])
     torch.cuda.synchronize(dev)
     ddist.barrier()
     dt = time.perf_counter() - t0
     prof = ops.gemm_profile_stop()
+    if os.environ.get("DYN_DEBUG_HOST"):
+        print(f"[host] wall {dt:.3f} s, blocked on pseudo-label ids {lib.HOST_WAIT[0]:.3f} s (incl. warm-up)", file=sys.stderr)
     dt = ddist.max_over_ranks(dt)
     # the path's one collective: WER counters over RCCL (outside the timed region, as in the reference harness)
     counts = ddist.all_reduce_counts(edit_counts([tok.decode(h) for h in hyps], [tok.decode(h) for h in hyps]))
@@ -163,6 +175,7 @@ def main():
                                    "6 freq masks <=34), SCConformerXL 6x768 V+1=4096 seeded weights",
                        "recording_seconds": a.seconds, "windows_per_recording": len(lib.prepare_chunks(specs[0], a.seq_len, a.overlap)[1]),
                        "sharding": f"{world} ranks x {a.steps} recordings, no data-path collective",
+                       "chains_per_gpu": n_chains, "hip_graphs": bool(a.graphs),
                        "blank_bias": round(a.blank_bias, 4), "hyp_tokens_per_recording": [len(h) for h in hyps]},
             "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -170,7 +183,9 @@ def main():
                          "algorithmic_bytes_per_launch": round(prof["bytes"] / prof["calls"]) if prof and prof["calls"] else None,
                          "flop_per_launch": round(prof["flops"] / prof["calls"]) if prof and prof["calls"] else None,
                          "gemm_launches": prof["calls"] if prof else 0, "sampled_launches": prof["sampled"] if prof else 0,
-                         "gemm_tflop_per_step": round(prof["flops"] / a.steps / 1e12, 2) if prof else None},
+                         "gemm_tflop_per_step": round(prof["flops"] * (16 if a.graphs else 1) / a.steps / 1e12, 2) if prof else None,
+                         "sampling": "every 4th GEMM launch of every 16th window step (those steps run eagerly; the rest replay hipGraphs)"
+                                     if a.graphs else "every 4th GEMM launch"},
             "wer_counters": list(counts),
         }
         if world == 1 and not a.no_cpu_baseline:

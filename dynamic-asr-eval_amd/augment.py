@@ -39,15 +39,19 @@ class SpecAugment:
         return fm, tm
 
     def apply(self, window, masks, fill_value):
-        """window: contiguous CUDA [F, T]; masks = ((f_starts, f_widths), (t_starts, t_widths))."""
-        (f0, fw), (t0, tw) = masks
-        dev = window.device
-        if f0:
-            ops.specaug_freqmask(window, torch.tensor(f0, dtype=torch.int32, device=dev),
-                                 torch.tensor(fw, dtype=torch.int32, device=dev), fill_value)
-        if t0:
-            ops.specaug_timemask(window, torch.tensor(t0, dtype=torch.int32, device=dev),
-                                 torch.tensor(tw, dtype=torch.int32, device=dev), fill_value)
+        """window: contiguous CUDA [F, T]; masks = ((f_starts, f_widths), (t_starts, t_widths)); fill_value: float or a
+        1-element device tensor.  Mask positions travel as kernel arguments (no H2D copy, no host stall)."""
+        import ctypes
+        from ._lib import check, load
+        F, T = window.shape
+        vdev = fill_value.data_ptr() if isinstance(fill_value, torch.Tensor) else 0
+        val = 0.0 if vdev else float(fill_value)
+        for along_time, (st, wd) in ((0, masks[0]), (1, masks[1])):
+            for i in range(0, len(st), 32):
+                a = (ctypes.c_int32 * len(st[i:i + 32]))(*st[i:i + 32])
+                b = (ctypes.c_int32 * len(wd[i:i + 32]))(*wd[i:i + 32])
+                check(load().dyn_specaug_mask_args(window.data_ptr(), F, T, ctypes.addressof(a), ctypes.addressof(b), len(a), along_time,
+                                                   val, vdev, torch.cuda.current_stream().cuda_stream), "dyn_specaug_mask_args")
         return window
 
 

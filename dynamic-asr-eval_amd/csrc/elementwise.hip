@@ -144,7 +144,8 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, float*
 
 // SpecAugment frequency masking on a [F, T] log-mel window: rows f0[k] <= f < f0[k]+w[k] set to `value`.
 __global__ void freq_mask_kernel(float* x, int F, int64_t T, const int32_t* __restrict__ f0, const int32_t* __restrict__ w,
-                                 int n_masks, float value) {
+                                 int n_masks, float value, const float* __restrict__ value_dev) {
+    if (value_dev) value = *value_dev;
     const int f = blockIdx.y;
     bool hit = false;
     for (int k = 0; k < n_masks; ++k) hit |= (f >= f0[k] && f < f0[k] + w[k]);
@@ -154,7 +155,8 @@ __global__ void freq_mask_kernel(float* x, int F, int64_t T, const int32_t* __re
 
 // SpecAugment time masking: columns t0[k] <= t < t0[k]+w[k] of every row set to `value`.
 __global__ void time_mask_kernel(float* x, int F, int64_t T, const int32_t* __restrict__ t0, const int32_t* __restrict__ w,
-                                 int n_masks, float value) {
+                                 int n_masks, float value, const float* __restrict__ value_dev) {
+    if (value_dev) value = *value_dev;
     const int k = blockIdx.y;
     const int64_t a = t0[k], wd = w[k];
     const int64_t total = (int64_t)F * wd;
@@ -255,24 +257,24 @@ extern "C" int dyn_reduce_partials(const float* partial, float* out, int64_t P, 
 }
 
 extern "C" int dyn_specaug_freqmask(float* x, int64_t F, int64_t T, const int32_t* f0, const int32_t* width,
-                                    int64_t n_masks, float value, void* stream) {
+                                    int64_t n_masks, float value, const float* value_dev, void* stream) {
     DYN_REQUIRE(x && F > 0 && T >= 0 && n_masks >= 0 && (n_masks == 0 || (f0 && width)), DYN_E_ARG,
                 "dyn_specaug_freqmask: bad arguments");
     if (T == 0 || n_masks == 0) return DYN_OK;
     int64_t gx = dyn::cdiv(T, TPB * 4);
     if (gx > 256) gx = 256;
     hipLaunchKernelGGL(freq_mask_kernel, dim3((unsigned)gx, (unsigned)F), dim3(TPB), 0, (hipStream_t)stream, x, (int)F, T,
-                       f0, width, (int)n_masks, value);
+                       f0, width, (int)n_masks, value, value_dev);
     return dyn::check_launch("dyn_specaug_freqmask");
 }
 
 extern "C" int dyn_specaug_timemask(float* x, int64_t F, int64_t T, const int32_t* t0, const int32_t* width, int64_t n_masks,
-                                    float value, void* stream) {
+                                    float value, const float* value_dev, void* stream) {
     DYN_REQUIRE(x && F > 0 && T >= 0 && n_masks >= 0 && (n_masks == 0 || (t0 && width)), DYN_E_ARG,
                 "dyn_specaug_timemask: bad arguments");
     if (T == 0 || n_masks == 0) return DYN_OK;
     hipLaunchKernelGGL(time_mask_kernel, dim3(64, (unsigned)n_masks), dim3(TPB), 0, (hipStream_t)stream, x, (int)F, T, t0, width,
-                       (int)n_masks, value);
+                       (int)n_masks, value, value_dev);
     return dyn::check_launch("dyn_specaug_timemask");
 }
 

@@ -132,14 +132,16 @@ def _is_native(model):
 
 
 def _window_fill_value(window, zero_masking):
+    """Fill value of the SpecAugment masks: 0, or the window mean as a 1-element DEVICE tensor (dyn_moments) so that it
+    never makes a host round trip."""
     if zero_masking:
         return 0.0
-    F, T = window.shape
-    tmp = torch.zeros(T, device=window.device, dtype=torch.float32)
-    ops.colsum(window, tmp, beta=0.0)
-    tot = torch.zeros(1, device=window.device, dtype=torch.float32)
-    ops.colsum(tmp.view(T, 1), tot, beta=0.0)
-    return float(tot.item()) / float(F * T)
+    from ._lib import check, load
+    out = torch.empty(3, device=window.device, dtype=torch.float32)
+    ws = ops.workspace(window.device)
+    check(load().dyn_moments(window.data_ptr(), window.numel(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                             torch.cuda.current_stream().cuda_stream), "dyn_moments")
+    return out[1:2]
 
 
 def _unsupported(name):
@@ -162,7 +164,7 @@ def entropy_augmentation(spec, model, **kwargs):
     return spec
 
 
-def dynamic_eval_ctc_loss(
+def _dynamic_eval_gen(
         args,
         model,
         spec: torch.Tensor,
@@ -176,9 +178,9 @@ def dynamic_eval_ctc_loss(
         return_params: bool = False,
         return_device: bool = False,
 ):
-    """Reference lcasr/lib.py:450-640.  Returns np.float32 [T_ds, V+1] log-probs (and the adapted parameters as CPU
-    clones when `return_params`).  `return_device=True` (extension) returns the stitched log-probs as a CUDA tensor so
-    the harness can decode them without a PCIe round trip."""
+    """Generator form of dynamic_eval_ctc_loss: yields where the host would otherwise block on the GPU (the per-window
+    pseudo-label ids) or has queued a batch of independent work, so a driver can interleave several recording chains on
+    separate streams from ONE host thread (dynamic_eval_many).  The return value travels in StopIteration.value."""
     if beam_search_fn is not None and args.__dict__.get('lm_tta_beams', 3) != 0:
         _unsupported("LM beam-search pseudo-labels (beam_search_fn)")
     device = model.device
@@ -270,6 +272,10 @@ def dynamic_eval_ctc_loss(
         stitch["pos"] += ds_len
         stitch["end"] = max(stitch["end"], stitch["pos"])
 
+    pinned = None
+    tgt_ring, tgt_turn = None, 0
+    if native:
+        model.use_graphs = bool(args.__dict__.get('use_graphs', True))   # hipGraph replay of the per-window launch sequences
     model.eval()  # don't update batchrenorm (reference lib.py:525)
     training_data, training_keys = prepare_chunks(spec_dev, seq_len, overlap)
     for epoch in range(args.__dict__.get('epochs', 1)):
@@ -280,6 +286,7 @@ def dynamic_eval_ctc_loss(
         epochs_stime = time.time()
         pbar = tqdm(training_keys) if use_tqdm else training_keys
         for i in pbar:
+            ops.gemm_profile_tick()
             view = training_data[i][0]  # [F, u_len] view into the recording
             u_len = view.shape[-1]
             audio_chunk = torch.empty(num_negatives + 1, Fq, u_len, device=device, dtype=torch.float32)
@@ -300,13 +307,34 @@ def dynamic_eval_ctc_loss(
                 out = model(audio_signal=audio_chunk)
             post = out['final_posteriors']  # [B, N, C] on device
 
-            pseudo_targets = decoder(post[-1].detach())  # greedy ids on device -> text (reference lib.py:559)
+            # greedy ids on device (reference lib.py:559); only the ids cross PCIe, asynchronously into pinned memory
+            ids_dev, n_dev = ops.ctc_greedy(post[-1].detach(), blank)
+            if pinned is None or pinned[0].shape[1] < ids_dev.shape[1]:
+                pinned = (torch.empty(1, ids_dev.shape[1], dtype=torch.int32, pin_memory=True), torch.empty(1, dtype=torch.int32, pin_memory=True))
+            pinned[0][:, :ids_dev.shape[1]].copy_(ids_dev, non_blocking=True)
+            pinned[1].copy_(n_dev, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record()
+            yield                                            # another chain may use the host while this forward runs
+            _t0 = time.perf_counter()
+            ready.synchronize()
+            HOST_WAIT[0] += time.perf_counter() - _t0
+            pseudo_targets = tokenizer.decode(pinned[0][0, :int(pinned[1][0])].tolist())
             if verbose and not args.__dict__.get('not_verbose', False) and args.__dict__.get('print_predictions', False):
                 print(f'Pseudo targets: {pseudo_targets}')
                 print(f'Noisy predictions: {decoder(post[0].detach())}\n--\n')
             target_ids = tokenizer.encode(pseudo_targets)  # text hop kept (reference lib.py:569)
             S = len(target_ids)
-            targets = torch.tensor([target_ids if S else [0]] * num_negatives, dtype=torch.int32, device=device)
+            # pseudo-label ids go up through a small ring of pinned buffers with an async copy (a pageable upload would
+            # block the host on this stream); a slot is reused 4 windows later, long after its copy has run
+            if tgt_ring is None or tgt_ring[0].shape[1] < max(S, 1):
+                tgt_ring = [torch.empty(num_negatives, max(2 * S, 256), dtype=torch.int32, pin_memory=True) for _ in range(4)]
+            slot = tgt_ring[tgt_turn % 4]
+            tgt_turn += 1
+            row = torch.as_tensor(target_ids if S else [0], dtype=torch.int32)
+            slot[:, :row.numel()] = row
+            targets = torch.empty(num_negatives, max(S, 1), dtype=torch.int32, device=device)
+            targets.copy_(slot[:, :max(S, 1)], non_blocking=True)
             augmented_outs = post[:num_negatives]
             N, B = augmented_outs.shape[1], augmented_outs.shape[0]
             total_tokens_in_loss = N * B
@@ -353,6 +381,7 @@ def dynamic_eval_ctc_loss(
                 while len(group) < final_batch and idx + len(group) < len(keys) and \
                         training_data[keys[idx + len(group)]].shape[-1] == u_len:
                     group.append(keys[idx + len(group)])
+                ops.gemm_profile_tick()
                 batch = torch.empty(len(group), Fq, u_len, device=device, dtype=torch.float32)
                 for b, k in enumerate(group):
                     batch[b].copy_(training_data[k][0])
@@ -360,6 +389,7 @@ def dynamic_eval_ctc_loss(
                 for b, k in enumerate(group):
                     stitch_window(k, post[b], u_len)
                 idx += len(group)
+                yield                                        # independent forwards are queued: let another chain enqueue
         if print_runtimes:
             torch.cuda.synchronize(device)
             print(f'Final pass runtime: {time.time() - final_pass_stime}')
@@ -380,6 +410,60 @@ def dynamic_eval_ctc_loss(
 
     logits = logits_dev if return_device else logits_dev.cpu().numpy()
     return logits if not return_params else (logits, updated_model_params)
+
+
+def dynamic_eval_ctc_loss(args, model, spec, seq_len, overlap, tokenizer, use_tqdm=True, optim=MADGRAD, optimizer_state=None,
+                          beam_search_fn=None, return_params=False, return_device=False):
+    """Reference lcasr/lib.py:450-640.  Returns np.float32 [T_ds, V+1] log-probs (and the adapted parameters as CPU
+    clones when `return_params`).  `return_device=True` (extension) returns the stitched log-probs as a CUDA tensor so
+    the harness can decode them without a PCIe round trip."""
+    gen = _dynamic_eval_gen(args, model, spec, seq_len, overlap, tokenizer, use_tqdm=use_tqdm, optim=optim,
+                            optimizer_state=optimizer_state, beam_search_fn=beam_search_fn, return_params=return_params,
+                            return_device=return_device)
+    try:
+        while True:
+            next(gen)
+    except StopIteration as stop:
+        return stop.value
+
+
+_CHAIN_STREAMS = {}
+HOST_WAIT = [0.0]   # seconds the host spent blocked on the per-window pseudo-label ids (diagnostic)
+
+
+def dynamic_eval_many(args, models, specs, seq_len, overlap, tokenizer, **kw):
+    """Several recordings in flight on ONE GPU from one host thread: each model replica in `models` owns a HIP stream and
+    runs one recording at a time; the chains are advanced round-robin at their yield points, so the GEMMs of one chain fill
+    the latency-bound stretches of the other (CTC scans, the pseudo-label round trip, short HBM-bound kernels).
+    Recordings are independent (reference lib.py:494,636-637).  Returns the per-recording results in `specs` order."""
+    device = models[0].device
+    key = torch.device(device).index
+    while len(_CHAIN_STREAMS.setdefault(key, [])) < len(models):    # streams are kept: the caching allocator's per-stream
+        _CHAIN_STREAMS[key].append(torch.cuda.Stream(device=device))  # pools stay warm across calls (no hipMalloc in the loop)
+    streams = _CHAIN_STREAMS[key][:len(models)]
+    main = torch.cuda.current_stream(device)
+    for st in streams:
+        st.wait_stream(main)
+    pending = list(enumerate(specs))
+    results = [None] * len(specs)
+    free, active = list(range(len(models)))[::-1], []
+    while pending or active:
+        while pending and free:
+            ci = free.pop()
+            idx, spec = pending.pop(0)
+            active.append([_dynamic_eval_gen(args, models[ci], spec, seq_len, overlap, tokenizer, **kw), ci, idx])
+        for item in list(active):
+            gen, ci, idx = item
+            with torch.cuda.stream(streams[ci]):
+                try:
+                    next(gen)
+                except StopIteration as stop:
+                    results[idx] = stop.value
+                    active.remove(item)
+                    free.append(ci)
+    for st in streams:
+        main.wait_stream(st)
+    return results
 
 
 dynamic_eval = dynamic_eval_ctc_loss

@@ -54,9 +54,11 @@ def _opt(t, name, dtype=F32):
 
 
 def workspace(device=None):
-    """One caller-owned scratch buffer per device (split-K slabs, partial reductions, CTC lattice)."""
+    """One caller-owned scratch buffer per (device, stream): split-K slabs, partial reductions, CTC lattice.  Per stream
+    because concurrent recording chains (concurrency.py) must not share scratch."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
@@ -104,10 +106,30 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha
 GEMM_PROFILE = None
 
 
-def gemm_profile_start(every=8):
-    """Sample every `every`-th GEMM launch with a HIP-event pair (bench.py's live roofline measurement)."""
+def GEMM_PROFILE_EAGER():
+    """True while bench.py's per-launch HIP-event sampling wants THIS model call to run eagerly (graph replays cannot be
+    timed launch by launch): every `window_every`-th forward/backward pair of the timed region."""
+    prof = GEMM_PROFILE
+    if prof is None or not prof.get("window_every"):
+        return False
+    return prof["eager_now"]
+
+
+def gemm_profile_start(every=8, window_every=0):
+    """Sample every `every`-th GEMM launch with a HIP-event pair (bench.py's live roofline measurement).  With hipGraph
+    replay enabled, `window_every` = n makes every n-th window step run eagerly (gemm_profile_tick) so its launches can
+    be sampled; launch counters then cover the eager windows only."""
     global GEMM_PROFILE
-    GEMM_PROFILE = {"calls": 0, "flops": 0.0, "bytes": 0.0, "every": int(every), "samples": []}
+    GEMM_PROFILE = {"calls": 0, "flops": 0.0, "bytes": 0.0, "every": int(every), "samples": [], "window_every": int(window_every),
+                    "windows": 0, "eager_now": False}
+
+
+def gemm_profile_tick():
+    """Called once per window step by the dynamic-eval loop: decides whether this step runs eagerly (sampled)."""
+    prof = GEMM_PROFILE
+    if prof is not None and prof.get("window_every"):
+        prof["eager_now"] = prof["windows"] % prof["window_every"] == 0
+        prof["windows"] += 1
 
 
 def gemm_profile_stop():
@@ -216,10 +238,12 @@ def transpose_ft(x, out=None):
 
 
 def specaug_freqmask(x, f0, width, value=0.0):
-    """In-place frequency masks on a contiguous [F, T] window; f0/width are int32 CUDA tensors."""
+    """In-place frequency masks on a contiguous [F, T] window; f0/width are int32 CUDA tensors; `value` may be a float or
+    a 1-element CUDA tensor (device-side fill value: no host round trip)."""
     _cc(x, "specaug.x"); _cc(f0, "specaug.f0", I32); _cc(width, "specaug.width", I32)
     F, T = x.shape
-    check(_L().dyn_specaug_freqmask(x.data_ptr(), F, T, f0.data_ptr(), width.data_ptr(), f0.numel(), value, _stream()),
+    vdev = value.data_ptr() if isinstance(value, torch.Tensor) else 0
+    check(_L().dyn_specaug_freqmask(x.data_ptr(), F, T, f0.data_ptr(), width.data_ptr(), f0.numel(), 0.0 if vdev else value, vdev, _stream()),
           "dyn_specaug_freqmask")
     return x
 
@@ -228,7 +252,8 @@ def specaug_timemask(x, t0, width, value=0.0):
     """In-place time masks on a contiguous [F, T] window."""
     _cc(x, "specaug.x"); _cc(t0, "specaug.t0", I32); _cc(width, "specaug.width", I32)
     F, T = x.shape
-    check(_L().dyn_specaug_timemask(x.data_ptr(), F, T, t0.data_ptr(), width.data_ptr(), t0.numel(), value, _stream()),
+    vdev = value.data_ptr() if isinstance(value, torch.Tensor) else 0
+    check(_L().dyn_specaug_timemask(x.data_ptr(), F, T, t0.data_ptr(), width.data_ptr(), t0.numel(), 0.0 if vdev else value, vdev, _stream()),
           "dyn_specaug_timemask")
     return x
 

@@ -156,11 +156,18 @@ int dyn_rotary(float* x, const float* cos_table, const float* sin_table, int64_t
 
 /* SpecAugment frequency masks on a [F, T] log-mel window, in place: rows f0[k] <= f < f0[k]+width[k] := value.
  * Replaces lcasr.utils.augmentation.SpecAugment as called at reference lcasr/lib.py:499,541 (mask positions are
- * drawn on the host so the RNG stream stays the caller's). */
+ * drawn on the host so the RNG stream stays the caller's).  value_dev (nullable) overrides `value` with a DEVICE scalar,
+ * e.g. the window mean produced by dyn_moments, so the fill value never makes a host round trip. */
 int dyn_specaug_freqmask(float* x, int64_t F, int64_t T, const int32_t* f0, const int32_t* width, int64_t n_masks,
-                         float value, void* stream);
+                         float value, const float* value_dev, void* stream);
 int dyn_specaug_timemask(float* x, int64_t F, int64_t T, const int32_t* t0, const int32_t* width, int64_t n_masks,
-                         float value, void* stream);
+                         float value, const float* value_dev, void* stream);
+
+/* Same masking with the (start, width) pairs passed by value as kernel arguments: start_host / width_host are HOST arrays
+ * (n_masks <= 32) read at launch time, so the per-window loop has no device index buffer and no blocking
+ * host-to-device copy (a pageable copy would make the host wait for the previous window's backward). */
+int dyn_specaug_mask_args(float* x, int64_t F, int64_t T, const int32_t* start_host, const int32_t* width_host, int64_t n_masks,
+                          int32_t along_time, float value, const float* value_dev, void* stream);
 
 /* Log-mel front end (upstream lcasr.utils.audio_tools.processing_chain, called by the dataset adapters: reference
  * lcasr/earnings22/run.py:61, tedlium/run.py:94, chime6/run.py:61-68).  The STFT itself is a dyn_gemm_f32 call on the
