@@ -286,7 +286,10 @@ def _dynamic_eval_gen(
         epochs_stime = time.time()
         pbar = tqdm(training_keys) if use_tqdm else training_keys
         for i in pbar:
-            ops.gemm_profile_tick()
+            sampled = ops.gemm_profile_tick()   # bench.py's live roofline sampling (0 = off)
+            if sampled == 2:
+                torch.cuda.synchronize(device)   # exclusive sample: the other chains' queued work drains first
+            ops.gemm_profile_mode(sampled)
             view = training_data[i][0]  # [F, u_len] view into the recording
             u_len = view.shape[-1]
             audio_chunk = torch.empty(num_negatives + 1, Fq, u_len, device=device, dtype=torch.float32)
@@ -315,10 +318,15 @@ def _dynamic_eval_gen(
             pinned[1].copy_(n_dev, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record()
+            if sampled == 2:
+                ready.synchronize()
             yield                                            # another chain may use the host while this forward runs
             _t0 = time.perf_counter()
+            if sampled == 2:
+                torch.cuda.synchronize(device)
             ready.synchronize()
             HOST_WAIT[0] += time.perf_counter() - _t0
+            ops.gemm_profile_mode(sampled)
             pseudo_targets = tokenizer.decode(pinned[0][0, :int(pinned[1][0])].tolist())
             if verbose and not args.__dict__.get('not_verbose', False) and args.__dict__.get('print_predictions', False):
                 print(f'Pseudo targets: {pseudo_targets}')
@@ -361,6 +369,8 @@ def _dynamic_eval_gen(
 
             if online:
                 stitch_window(i, post[-1].detach(), u_len)
+            if sampled == 2:
+                torch.cuda.current_stream(device).synchronize()
         epochs_etime = time.time()
         if print_runtimes:
             torch.cuda.synchronize(device)
@@ -373,23 +383,28 @@ def _dynamic_eval_gen(
         final_pass_stime = time.time()
         keys = sorted(training_keys)
         idx = 0
-        with torch.no_grad():
-            while idx < len(keys):
-                # windows are independent here: batch equal-length ones to fill the GPU (reference: B = 1, lib.py:599-609)
-                group = [keys[idx]]
-                u_len = training_data[keys[idx]].shape[-1]
-                while len(group) < final_batch and idx + len(group) < len(keys) and \
-                        training_data[keys[idx + len(group)]].shape[-1] == u_len:
-                    group.append(keys[idx + len(group)])
-                ops.gemm_profile_tick()
-                batch = torch.empty(len(group), Fq, u_len, device=device, dtype=torch.float32)
-                for b, k in enumerate(group):
-                    batch[b].copy_(training_data[k][0])
+        while idx < len(keys):
+            # windows are independent here: batch equal-length ones to fill the GPU (reference: B = 1, lib.py:599-609)
+            group = [keys[idx]]
+            u_len = training_data[keys[idx]].shape[-1]
+            while len(group) < final_batch and idx + len(group) < len(keys) and \
+                    training_data[keys[idx + len(group)]].shape[-1] == u_len:
+                group.append(keys[idx + len(group)])
+            sampled = ops.gemm_profile_tick()
+            if sampled == 2:
+                torch.cuda.synchronize(device)
+            ops.gemm_profile_mode(sampled)
+            batch = torch.empty(len(group), Fq, u_len, device=device, dtype=torch.float32)
+            for b, k in enumerate(group):
+                batch[b].copy_(training_data[k][0])
+            with torch.no_grad():   # never held across a yield: interleaved generators would restore each other's grad mode
                 post = model(audio_signal=batch)['final_posteriors']
                 for b, k in enumerate(group):
                     stitch_window(k, post[b], u_len)
-                idx += len(group)
-                yield                                        # independent forwards are queued: let another chain enqueue
+            idx += len(group)
+            if sampled == 2:
+                torch.cuda.current_stream(device).synchronize()
+            yield                                        # independent forwards are queued: let another chain enqueue
         if print_runtimes:
             torch.cuda.synchronize(device)
             print(f'Final pass runtime: {time.time() - final_pass_stime}')

@@ -119,6 +119,7 @@ class SCConformerXL:
         self.layers = [_Group(self, f"layers.{l}.") for l in range(cfg["n_layers"])]
         self.decoder = _Group(self, "decoder.", num_classes=self.num_classes)
         self._rot = {}
+        self._ws = None             # this model's scratch buffer (ops.use_workspace): never shared with another chain
         self._ctx = None
         self._skip_wgrad = False
         self.use_graphs = False     # hipGraph replay of the forward / backward launch sequences (see forward())
@@ -201,7 +202,16 @@ class SCConformerXL:
     def __call__(self, audio_signal=None, **kw):
         return self.forward(audio_signal)
 
+    def _scratch(self):
+        if self._ws is None:
+            self._ws = torch.empty(ops.WORKSPACE_BYTES, dtype=torch.uint8, device=self.device)
+        return self._ws
+
     def forward(self, audio_signal):
+        with ops.use_workspace(self._scratch()):
+            return self._forward(audio_signal)
+
+    def _forward(self, audio_signal):
         """Eager launch sequence, or — with `use_graphs` — a hipGraph replay of it.  A (shape, grad-mode) pair is captured
         the second time it is seen (one-off shapes such as the short last window stay eager); the captured graph owns its
         activations (static addresses), so the matching backward graph can be captured once and replayed too.  One window
@@ -377,9 +387,10 @@ class SCConformerXL:
         product (the entropy-gradient input perturbation, reference lib.py:96, needs only the input gradient)."""
         self._skip_wgrad = not param_grads
         try:
-            if self._ctx_static and self.use_graphs and not input_grad and param_grads and self._ctx is not None:
-                return self._backward_graphed(grad_posteriors, n_active)
-            return self._backward(grad_posteriors, n_active, input_grad)
+            with ops.use_workspace(self._scratch()):
+                if self._ctx_static and self.use_graphs and not input_grad and param_grads and self._ctx is not None:
+                    return self._backward_graphed(grad_posteriors, n_active)
+                return self._backward(grad_posteriors, n_active, input_grad)
         finally:
             self._skip_wgrad = False
 

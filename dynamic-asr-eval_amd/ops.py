@@ -53,9 +53,31 @@ def _opt(t, name, dtype=F32):
     return 0 if t is None else _cc(t, name, dtype).data_ptr()
 
 
+_WS_OWNER = None   # scratch buffer of the model whose forward/backward is being launched or captured (use_workspace)
+
+
+class use_workspace:
+    """Route every op's scratch to `ws` while a model launches (or captures) its kernels.  A stream-keyed lookup is wrong
+    inside a hipGraph capture: torch captures on its own side stream, so two models' graphs would be handed the same
+    scratch buffer and race when their replays overlap on different streams."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __enter__(self):
+        global _WS_OWNER
+        self.prev, _WS_OWNER = _WS_OWNER, self.ws
+
+    def __exit__(self, *exc):
+        global _WS_OWNER
+        _WS_OWNER = self.prev
+
+
 def workspace(device=None):
-    """One caller-owned scratch buffer per (device, stream): split-K slabs, partial reductions, CTC lattice.  Per stream
-    because concurrent recording chains (concurrency.py) must not share scratch."""
+    """Caller-owned scratch (split-K slabs, partial reductions, CTC lattice): the launching model's own buffer inside
+    use_workspace(), otherwise one buffer per (device, stream) — concurrent recording chains must not share scratch."""
+    if _WS_OWNER is not None:
+        return _WS_OWNER
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (idx, torch.cuda.current_stream(idx).cuda_stream)
@@ -97,7 +119,7 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha
             e0.record()
             check(_L().dyn_gemm_f32(ctypes.byref(d), _stream()), "dyn_gemm_f32")
             e1.record()
-            prof["samples"].append((2.0 * M * N * K * nb1 * nb2, e0, e1))
+            prof["samples_excl" if prof.get("exclusive_now") else "samples"].append((2.0 * M * N * K * nb1 * nb2, e0, e1))
             return c
     check(_L().dyn_gemm_f32(ctypes.byref(d), _stream()), "dyn_gemm_f32")
     return c
@@ -120,16 +142,31 @@ def gemm_profile_start(every=8, window_every=0):
     replay enabled, `window_every` = n makes every n-th window step run eagerly (gemm_profile_tick) so its launches can
     be sampled; launch counters then cover the eager windows only."""
     global GEMM_PROFILE
-    GEMM_PROFILE = {"calls": 0, "flops": 0.0, "bytes": 0.0, "every": int(every), "samples": [], "window_every": int(window_every),
-                    "windows": 0, "eager_now": False}
+    GEMM_PROFILE = {"calls": 0, "flops": 0.0, "bytes": 0.0, "every": int(every), "samples": [], "samples_excl": [],
+                    "window_every": int(window_every), "windows": 0, "eager_now": False, "exclusive_now": False}
 
 
 def gemm_profile_tick():
-    """Called once per window step by the dynamic-eval loop: decides whether this step runs eagerly (sampled)."""
+    """Called once per window step by the dynamic-eval loop: decides whether this step runs eagerly (sampled).
+    -> 0 not sampled, 1 sampled as it runs (other chains may share the GPU), 2 sampled EXCLUSIVELY (the caller drains the
+    device before and after, so each timed launch has the GPU to itself: the kernel's own duration).  Sampled steps
+    alternate between the two kinds; with a single chain both are the same thing."""
     prof = GEMM_PROFILE
-    if prof is not None and prof.get("window_every"):
-        prof["eager_now"] = prof["windows"] % prof["window_every"] == 0
-        prof["windows"] += 1
+    if prof is None or not prof.get("window_every"):
+        return 0
+    kind = 0
+    if prof["windows"] % prof["window_every"] == 0:
+        kind = 2 if (prof["windows"] // prof["window_every"]) % 2 == 0 else 1
+    prof["windows"] += 1
+    return kind
+
+
+def gemm_profile_mode(kind):
+    """Set by the dynamic-eval loop right before each model call of a step (chains interleave on one host thread)."""
+    prof = GEMM_PROFILE
+    if prof is not None:
+        prof["eager_now"] = kind > 0
+        prof["exclusive_now"] = kind == 2
 
 
 def gemm_profile_stop():
@@ -138,10 +175,11 @@ def gemm_profile_stop():
     prof, GEMM_PROFILE = GEMM_PROFILE, None
     if prof is None:
         return None
-    fl = sum(s[0] for s in prof["samples"])
-    ms = sum(s[1].elapsed_time(s[2]) for s in prof["samples"])
-    return {"calls": prof["calls"], "flops": prof["flops"], "bytes": prof["bytes"], "sampled": len(prof["samples"]),
-            "sampled_flops": fl, "sampled_ms": ms}
+    out = {"calls": prof["calls"], "flops": prof["flops"], "bytes": prof["bytes"]}
+    for key, name in (("samples", "shared"), ("samples_excl", "exclusive")):
+        out[name] = {"sampled": len(prof[key]), "flops": sum(s[0] for s in prof[key]),
+                     "ms": sum(s[1].elapsed_time(s[2]) for s in prof[key])}
+    return out
 
 
 def linear(x, w, bias=None, out=None, alpha=1.0, beta=0.0, residual=None):

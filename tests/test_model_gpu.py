@@ -216,3 +216,46 @@ def test_fused_convmod_matches_unfused(cuda, conv_norm):
         hip.fused_convmod = True
         a = hip(audio_signal=x)['final_posteriors']
     assert (a - outs[0]).abs().max().item() < 1e-6
+
+
+def test_chains_and_graphs_are_bit_identical_to_the_sequential_eager_loop(cuda):
+    """dynamic_eval_many (recordings interleaved on several streams, hipGraph replay of the encoder) launches the same
+    kernels with the same plans as one eager recording after another: results must be bit-identical, every replica's
+    weights restored, and the caller's grad mode untouched (no grad-mode context is held across a generator yield)."""
+    from oracle.dynamic_eval_ref import prepare_chunks
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.model import SCConformerXL
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    vocab = 128
+    _, hip = _pair(cuda, SMALL, vocab=vocab, seed=5, blank_bias=1.5)
+    replicas = [hip]
+    for _ in range(2):
+        m = SCConformerXL(SMALL, vocab_size=vocab, device=cuda)
+        m.flat_params.copy_(hip.flat_params)
+        replicas.append(m)
+    tok = SyntheticTokenizer(vocab)
+    g = torch.Generator().manual_seed(21)
+    specs = [torch.randn(1, 80, n, generator=g) for n in (1500, 1100, 1500, 700, 1300)]   # ragged, more than chains
+    seq_len, overlap = 512, 256
+    # SpecAugment draws come from the global CPU RNG in call order, which interleaving changes: pin them per window key
+    _, keys = prepare_chunks(specs[0], seq_len, overlap)
+    masks = _masks_for(keys, 80, None, seed=9)
+
+    def args(graphs):
+        return _args(optim_lr=1e-4, quiet=True, use_graphs=graphs, spec_augment_fixed_masks=masks)
+
+    eager = [lib.dynamic_eval(args(False), hip, s, seq_len, overlap, tok, use_tqdm=False) for s in specs]
+    graphed = [lib.dynamic_eval(args(True), hip, s, seq_len, overlap, tok, use_tqdm=False) for s in specs]
+    for a_, b_ in zip(eager, graphed):
+        assert np.array_equal(a_, b_), "hipGraph replay must not change a single bit"
+    before = [m.flat_params.clone() for m in replicas]
+    many = lib.dynamic_eval_many(args(True), replicas, specs, seq_len, overlap, tok, use_tqdm=False)
+    assert len(many) == len(specs)
+    for a_, b_ in zip(eager, many):
+        assert a_.shape == b_.shape and np.array_equal(a_, b_), "interleaved chains must match the sequential loop bit for bit"
+    for m, b in zip(replicas, before):
+        assert torch.equal(m.flat_params, b), "every replica's weights must be restored"
+    assert torch.is_grad_enabled()
+    # the adaptation did something: the no-adapt pass differs
+    plain = lib.dynamic_eval(_args(epochs=0, quiet=True), hip, specs[0], seq_len, overlap, tok, use_tqdm=False)
+    assert np.abs(plain - eager[0]).max() > 1e-6

@@ -288,3 +288,27 @@ def test_optional_augmentations_match_reference_functions(cuda):
         torch.manual_seed(7); ref = R.cutout(spec.clone(), 600, cutout_val=val, num_rectangles=7, max_width=100, max_height=10)
         torch.manual_seed(7); got = augment.cutout(spec[0].to(cuda).clone(), 600, cutout_val=val, num_rectangles=7, max_width=100, max_height=10)
         _close(got, ref[0], 2e-6, f"cutout {val}")
+
+
+def test_specaug_mask_args_matches_device_index_kernels(cuda):
+    """dyn_specaug_mask_args (masks as kernel arguments) == dyn_specaug_freqmask / _timemask (masks in device buffers),
+    including > 32 masks (chunked), zero-width masks, and a device-resident fill value."""
+    from dynamic_asr_eval_amd import ops
+    from dynamic_asr_eval_amd.augment import SpecAugment
+    g = torch.Generator().manual_seed(3)
+    F, T = 80, 777
+    x = torch.randn(F, T, generator=g).to(cuda)
+    f0 = torch.randint(0, F - 10, (40,), generator=g).tolist(); fw = torch.randint(0, 10, (40,), generator=g).tolist()
+    t0 = torch.randint(0, T - 50, (5,), generator=g).tolist(); tw = torch.randint(0, 50, (5,), generator=g).tolist()
+    fill = torch.tensor([0.37], device=cuda)
+    a = x.clone(); b = x.clone()
+    ops.specaug_freqmask(a, torch.tensor(f0, dtype=torch.int32, device=cuda), torch.tensor(fw, dtype=torch.int32, device=cuda), fill)
+    ops.specaug_timemask(a, torch.tensor(t0, dtype=torch.int32, device=cuda), torch.tensor(tw, dtype=torch.int32, device=cuda), fill)
+    SpecAugment().apply(b, ((f0, fw), (t0, tw)), fill)
+    assert torch.equal(a, b)
+    c = x.clone()
+    SpecAugment().apply(c, ((f0[:3], fw[:3]), ([], [])), 0.0)
+    ref = x.clone()
+    for s_, w_ in zip(f0[:3], fw[:3]):
+        ref[s_:s_ + w_] = 0.0
+    assert torch.equal(c, ref)
