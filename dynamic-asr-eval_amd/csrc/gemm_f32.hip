@@ -18,6 +18,7 @@
 //   * split-K writes fp32 slabs to a caller workspace and a second kernel sums them in slice order:
 //     deterministic wgrad without float atomics.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -155,12 +156,68 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int roff,
     }
 }
 
-template <bool TA, bool TB, int BM, int BN, bool VEC>
+// ---- direct-to-LDS staging (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass --------------------------------
+// One wave-instruction writes 1 KiB of LDS linearly (wave-uniform base + lane * 16 B), so the LDS image is unpadded and the
+// bank-conflict-free layout is obtained by choosing which 16 B each lane FETCHES:
+//   K-contiguous operand: [row][32 floats]; the 16-B slot q (= k / 4) of row r lives at slot q ^ ((r >> 1) & 7), which puts
+//     every 16-lane ds_read_b128 group on 16 distinct slots of the 256-B bank row;
+//   row-contiguous operand: [k][R floats], read with ds_read_b32 (32 consecutive floats per lane half: conflict-free as is).
+// Rows past the matrix edge are clamped to the last valid row (group of 4): they only feed outputs that are never stored.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <bool KMAJOR, int R>
+struct GldsStager {
+    static constexpr int NI = R * BK / 1024;   // 1-KiB pieces per wave per tile (4 waves): R=128 -> 4, R=64 -> 2
+    const float* ptr[NI];
+    int64_t step;
+    __device__ __forceinline__ void init(const float* base, int64_t ld, int64_t row0, int64_t rows, int64_t k0, int wave, int lane) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = wave * NI + j;
+            if (KMAJOR) {
+                const int row = n * 8 + (lane >> 3);
+                const int q = (lane & 7) ^ ((row >> 1) & 7);
+                int64_t gr = row0 + row;
+                gr = gr < rows ? gr : rows - 1;
+                ptr[j] = base + gr * ld + k0 + 4 * q;
+            } else {
+                const int o = n * 256 + lane * 4;
+                const int k = o / R, col = o % R;
+                int64_t gr = row0 + col;
+                gr = gr < rows ? gr : rows - 4;
+                ptr[j] = base + (k0 + k) * ld + gr;
+            }
+        }
+        step = KMAJOR ? (int64_t)BK : (int64_t)BK * ld;
+    }
+    __device__ __forceinline__ void issue(float* tile, int wave) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)ptr[j], (lds_void_t*)(tile + (wave * NI + j) * 256), 16, 0, 0);
+            ptr[j] += step;
+        }
+    }
+};
+
+template <bool KMAJOR, int R>
+__device__ __forceinline__ void read_frag_glds(const float* __restrict__ s, int roff, int i, int h, int c, float (&f)[4]) {
+    if (KMAJOR) {
+        const float4 v = *reinterpret_cast<const float4*>(&s[(roff + i) * BK + 4 * ((2 * c + h) ^ ((i >> 1) & 7))]);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = s[(8 * c + 4 * h + q) * R + roff + i];
+    }
+}
+
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
     constexpr bool AK = !TA;  // A has K contiguous in HBM
     constexpr bool BKM = TB;  // B has K contiguous in HBM
     constexpr int WTM = BM / 64, WTN = BN / 64;  // 32x32 tiles per wave along M / N
-    constexpr int SA = BM * LDK, SB = BN * LDK;  // floats per stage (upper bound for both layouts)
+    static_assert(!GLDS || (VEC && BK == 32), "direct-to-LDS staging needs 16-B aligned operands and BK = 32");
+    constexpr int SA = GLDS ? BM * BK : BM * LDK, SB = GLDS ? BN * BK : BN * LDK;  // floats per stage
     __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
 
     // Work item of this workgroup.  Full items: XCD-aware bijective remap (blocks with equal blockIdx.x % 8 share an
@@ -223,40 +280,81 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
             load_tile<BKM, BN, VEC>(B, p.ldb, n0, p.N, k0, kend, rb);
         }
     };
-    if (nk > 0) {
+    GldsStager<AK, BM> stA;
+    GldsStager<BKM, BN> stB;
+    if (GLDS) {
+        stA.init(A, p.lda, m0, p.M, kbeg, wave, lane);
+        stB.init(B, p.ldb, n0, p.N, kbeg, wave, lane);
+        if (nk > 0) { stA.issue(smem, wave); stB.issue(smem + SA, wave); }
+    } else if (nk > 0) {
         fetch(kbeg);
         store_tile<AK, BM>(smem, ra);
         store_tile<BKM, BN>(smem + SA, rb);
     }
-    __syncthreads();
+    __syncthreads();   // with a direct-to-LDS load in flight this also waits vmcnt(0): the tile has landed
 
+    // Main loop, software-pipelined at two levels so a wave's MFMA stream never waits on LDS latency:
+    //   * fragments are double-buffered in registers: chunk c+1 is read from LDS while chunk c's MFMAs issue;
+    //   * the tile's LAST chunk is issued AFTER the barrier and after the next tile's first fragment reads, so the
+    //     ds_write + barrier + first ds_read latency of tile t+1 hides behind MFMAs of tile t.
+    // One barrier per K tile: tile t+1 is written to the other LDS buffer before it, and every read of tile t's buffer
+    // (the last chunk's fragments included) has been issued and waited for before it.
+    constexpr int NC = BK / 8;
+    constexpr int NREADS = (AK ? WTM : 4 * WTM) + (BKM ? WTN : 4 * WTN);   // LDS read instructions per chunk
+    static_assert(NC % 2 == 0, "the register ping-pong assumes an even number of k-chunks per tile");
+    float fa[2][WTM][4], fb[2][WTN][4];
+    auto read_chunk = [&](const float* sa, const float* sb, int c, int slot) {
+#pragma unroll
+        for (int a = 0; a < WTM; ++a) {
+            if (GLDS) read_frag_glds<AK, BM>(sa, wm * (BM / 2) + a * 32, i, h, c, fa[slot][a]);
+            else read_frag<AK, BM>(sa, wm * (BM / 2) + a * 32, i, h, c, fa[slot][a]);
+        }
+#pragma unroll
+        for (int b = 0; b < WTN; ++b) {
+            if (GLDS) read_frag_glds<BKM, BN>(sb, wn * (BN / 2) + b * 32, i, h, c, fb[slot][b]);
+            else read_frag<BKM, BN>(sb, wn * (BN / 2) + b * 32, i, h, c, fb[slot][b]);
+        }
+    };
+    auto mfma_chunk = [&](int slot) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int a = 0; a < WTM; ++a)
+#pragma unroll
+                for (int b = 0; b < WTN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][a][s], fb[slot][b][s], acc[a][b], 0, 0, 0);
+    };
     int cur = 0;
+    if (nk > 0) read_chunk(smem, smem + SA, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const float* sa = smem + cur * (SA + SB);
         const float* sb = sa + SA;
         const bool more = kt + 1 < nk;
-        if (more) fetch(kbeg + (int64_t)(kt + 1) * BK);
-#pragma unroll
-        for (int c = 0; c < BK / 8; ++c) {
-            float fa[WTM][4], fb[WTN][4];
-#pragma unroll
-            for (int a = 0; a < WTM; ++a) read_frag<AK, BM>(sa, wm * (BM / 2) + a * 32, i, h, c, fa[a]);
-#pragma unroll
-            for (int b = 0; b < WTN; ++b) read_frag<BKM, BN>(sb, wn * (BN / 2) + b * 32, i, h, c, fb[b]);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int a = 0; a < WTM; ++a)
-#pragma unroll
-                    for (int b = 0; b < WTN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
+        float* da = smem + (cur ^ 1) * (SA + SB);
+        if (GLDS) {
+            // the other buffer is free: its last fragment reads were waited for before the previous barrier
+            if (more) { stA.issue(da, wave); stB.issue(da + SA, wave); }
+        } else if (more) {
+            fetch(kbeg + (int64_t)(kt + 1) * BK);
         }
-        if (more) {
-            float* da = smem + (cur ^ 1) * (SA + SB);
+#pragma unroll
+        for (int c = 0; c < NC - 1; ++c) {
+            read_chunk(sa, sb, c + 1, (c + 1) & 1);
+            mfma_chunk(c & 1);
+            // pin the order the source states (LDS reads of the next chunk first, then this chunk's MFMAs): left alone,
+            // the scheduler sinks the reads to just before their first use and the MFMA stream stalls on LDS latency
+            __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * WTM * WTN, 0);
+        }
+        if (!GLDS && more) {
             store_tile<AK, BM>(da, ra);
             store_tile<BKM, BN>(da + SA, rb);
         }
         __syncthreads();
+        if (more) read_chunk(da, da + SA, 0, 0);
+        mfma_chunk((NC - 1) & 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * WTM * WTN, 0);
         cur ^= 1;
     }
 
@@ -472,8 +570,14 @@ Plan make_plan(const dyn_gemm_desc* d) {
 
 template <bool TA, bool TB, int BM, int BN>
 void launch_vec(const KParams& kp, bool vec, dim3 grid, hipStream_t st) {
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true>), grid, dim3(NTHREADS), 0, st, kp);
-    else hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, false>), grid, dim3(NTHREADS), 0, st, kp);
+    // direct-to-LDS staging: whole K tiles only (no zero fill), 16-B aligned operands, and an operand whose rows are the
+    // contiguous axis must have a row count that is a multiple of 4 (edge clamping works on 16-B groups)
+    static const bool allow_glds = [] { const char* e = getenv("DYN_GEMM_GLDS"); return !e || atoi(e) != 0; }();
+    const bool glds = allow_glds && vec && kp.K % BK == 0 && kp.K > 0 && (!TA || kp.M % 4 == 0) && (TB || kp.N % 4 == 0) &&
+                      (!TA || kp.M >= 4) && (TB || kp.N >= 4);
+    if (glds) hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true>), grid, dim3(NTHREADS), 0, st, kp);
+    else if (vec) hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, false>), grid, dim3(NTHREADS), 0, st, kp);
+    else hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, false, false>), grid, dim3(NTHREADS), 0, st, kp);
 }
 
 template <bool TA, bool TB>
