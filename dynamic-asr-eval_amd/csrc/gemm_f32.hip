@@ -491,7 +491,7 @@ struct Plan {
 // last round is the classic wave-quantisation loss, so when no global split-K is used its items are K-sliced tail_f ways
 // (tail_f = slots / remainder) and run as one short, full round.
 double tile_eff(int bm, int bn) { return (bm == 128 && bn == 128) ? 0.80 : (bm == 64 && bn == 64) ? 0.62 : 0.72; }
-int tile_occ(int bm, int bn) { return (bm == 64 && bn == 64) ? 4 : 2; }
+int tile_occ(int bm, int bn) { return (bm == 64 && bn == 64) ? 4 : (bm == 128 && bn == 128) ? 2 : 3; }  // resident workgroups per CU (LDS-bound)
 
 // One configuration: tile (bm, bn), global split-K s, tail slicing f_req (-1 = slots / remainder, 1 = off, n = forced).
 bool eval_config(const dyn_gemm_desc* d, int bm, int bn, int s, int f_req, Plan* out, double* cost) {
