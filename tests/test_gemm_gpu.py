@@ -68,3 +68,41 @@ def test_gemm_two_level_batch(cuda):
     kh = k.view(B, T, H, D).permute(0, 2, 1, 3).double().cpu()
     ref = 0.125 * qh @ kh.transpose(-1, -2)
     assert (s.double().cpu() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(100, 72, 64), (67, 129, 32), (1992, 200, 128), (260, 4, 96), (4, 260, 32)])
+@pytest.mark.parametrize("tile", [(128, 128, 1), (64, 64, 1), (128, 64, 3), (64, 128, 1)])
+def test_gemm_direct_to_lds_edges(cuda, ta, tb, M, N, K, tile):
+    """K % 32 == 0 and 16-B aligned operands select the direct-to-LDS kernel (when the row-contiguous operands have a row
+    count that is a multiple of 4; otherwise the register-staged kernel): ragged M/N edges are clamped loads there, so check
+    every tile shape against fp64 AND that nothing outside C[:M, :N] is touched (ldc > N, sentinel rows after M)."""
+    from dynamic_asr_eval_amd import ops
+    g = torch.Generator().manual_seed(M * 5 + N * 11 + K + tile[0])
+    a = torch.randn((K, M) if ta else (M, K), generator=g).to(cuda)
+    b = torch.randn((N, K) if tb else (K, N), generator=g).to(cuda)
+    ldc = N + 4
+    c = torch.full((M + 3, ldc), 7.25, device=cuda)
+    ops.gemm(a, b, c, trans_a=ta, trans_b=tb, M=M, N=N, K=K, lda=a.shape[1], ldb=b.shape[1], ldc=ldc, force=tile)
+    ref = _ref(a, b, ta, tb)
+    got = c.cpu()
+    err = (got[:M, :N].double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, K ** 0.5) * 4, err
+    assert torch.all(got[M:] == 7.25) and torch.all(got[:, N:] == 7.25), "wrote outside the M x N block"
+
+
+def test_gemm_direct_to_lds_matches_register_staged_bitwise(cuda):
+    """Both staging paths feed the MFMAs the same operands in the same k order: the results are bit-identical.  K = 96 runs
+    the direct-to-LDS kernel; the same product as two K = 48 halves accumulated (beta = 1) cannot be compared bitwise, so the
+    register-staged path is forced instead by a 4-B misaligned view of the same data (alignment is part of the dispatch)."""
+    from dynamic_asr_eval_amd import ops
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 300, 200, 96
+    a = torch.randn(M, K, generator=g).to(cuda)
+    b = torch.randn(N, K, generator=g).to(cuda)
+    c1 = torch.empty(M, N, device=cuda); c2 = torch.empty(M, N, device=cuda)
+    ops.gemm(a, b, c1, trans_b=True, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, force=(128, 128, 1))
+    buf_a = torch.empty(M * K + 1, device=cuda); buf_a[1:].copy_(a.flatten())
+    buf_b = torch.empty(N * K + 1, device=cuda); buf_b[1:].copy_(b.flatten())
+    ops.gemm(buf_a, buf_b, c2, trans_b=True, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_off=1, b_off=1, force=(128, 128, 1))
+    assert torch.equal(c1, c2)
