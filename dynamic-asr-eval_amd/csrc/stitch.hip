@@ -34,6 +34,20 @@ __global__ __launch_bounds__(TPB) void stitch_finalize_kernel(const float* __res
     }
 }
 
+// out[r, c] = log(acc[idx[r], c] / cnt[idx[r]]): the covered rows of an accumulator whose coverage has gaps
+// (audio-disjoint leave-one-out stitching, reference lcasr/run_within_recording_loo_eval.py:160-181)
+__global__ __launch_bounds__(TPB) void stitch_finalize_rows_kernel(const float* __restrict__ acc, const float* __restrict__ cnt,
+                                                                   const int64_t* __restrict__ idx, float* __restrict__ out,
+                                                                   int64_t rows, int C) {
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int64_t g = idx[r];
+        const float n = cnt[g];
+        const float* src = acc + g * C;
+        float* dst = out + r * C;
+        for (int c = threadIdx.x; c < C; c += TPB) dst[c] = logf(src[c] / n);
+    }
+}
+
 // x: rows of `row_stride` floats, the first n_heads * D of each row are [head][D] blocks to rotate (q and k).
 // (x1, x2) = (x[i], x[i + D/2]);  fwd: (x1 c - x2 s, x2 c + x1 s);  bwd (transpose): (g1 c + g2 s, g2 c - g1 s).
 __global__ __launch_bounds__(TPB) void rotary_kernel(float* __restrict__ x, const float* __restrict__ cos_t,
@@ -75,6 +89,15 @@ extern "C" int dyn_stitch_finalize(const float* acc, const float* count, float* 
     hipLaunchKernelGGL(stitch_finalize_kernel, dim3((unsigned)(rows < 8192 ? rows : 8192)), dim3(TPB), 0, (hipStream_t)stream, acc,
                        count, out, rows, (int)C);
     return dyn::check_launch("dyn_stitch_finalize");
+}
+
+extern "C" int dyn_stitch_finalize_rows(const float* acc, const float* count, const int64_t* row_index, float* out, int64_t rows,
+                                        int64_t C, void* stream) {
+    DYN_REQUIRE(acc && count && out && rows >= 0 && C > 0 && (rows == 0 || row_index), DYN_E_ARG, "dyn_stitch_finalize_rows: bad arguments");
+    if (rows == 0) return DYN_OK;
+    hipLaunchKernelGGL(stitch_finalize_rows_kernel, dim3((unsigned)(rows < 8192 ? rows : 8192)), dim3(TPB), 0, (hipStream_t)stream,
+                       acc, count, row_index, out, rows, (int)C);
+    return dyn::check_launch("dyn_stitch_finalize_rows");
 }
 
 extern "C" int dyn_rotary(float* x, const float* cos_table, const float* sin_table, int64_t B, int64_t T, int64_t n_heads,

@@ -585,6 +585,16 @@ def stitch_finalize(acc, count, rows):
     return out
 
 
+def stitch_finalize_rows(acc, count, row_index):
+    """log(acc / count) over the listed rows (int64 CUDA tensor): coverage with gaps."""
+    _cc(acc, "stitch.acc"); _cc(count, "stitch.count"); _c(row_index, "stitch.row_index", torch.int64)
+    C = acc.shape[1]
+    out = torch.empty(row_index.numel(), C, device=acc.device, dtype=F32)
+    check(_L().dyn_stitch_finalize_rows(acc.data_ptr(), count.data_ptr(), row_index.data_ptr(), out.data_ptr(), row_index.numel(), C,
+                                        _stream()), "dyn_stitch_finalize_rows")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- wav2vec2 pieces
 def gelu(x, out=None):
     _c(x, "gelu.x")

@@ -7,6 +7,8 @@ Differences, all about where work runs:
     torch.load(weights_only=True); without -c a seeded synthetic model of the yaml config is built (no checkpoint
     exists offline);
   * eval_fn returns device log-probs (return_device=True) and the final greedy decode runs on the GPU;
+  * `-kwargs chains=N` keeps N recordings in flight on each GPU (one model replica + HIP stream each, one host thread;
+    same transcripts as one at a time), see lib.dynamic_eval_many;
   * launched under torchrun with N ranks, recordings shard across the GPUs (longest first) and the edit counters /
     hypotheses are gathered over RCCL at the end; rank 0 prints and saves.
 Run:  python -m dynamic_asr_eval_amd.run_dynamic_eval_full -d synthetic -ds -epochs 1 -kwargs optim_lr=9e-5 …"""
@@ -73,10 +75,27 @@ def main(args):
     eval_fn = lib.AWMC if args.awmc else dynamic_eval                   # reference run_dynamic_eval_full.py:67-72
     mine = ddist.shard_longest_first([d.get('frames', 1) for d in data], world)[rank]
 
+    chains = int(args.__dict__.get('chains', 1))    # -kwargs chains=N: N recordings in flight per GPU (lib.dynamic_eval_many)
+    models = None
+    if chains > 1 and not args.awmc and len(mine) > 1:
+        from .run_seq_eval import replicate
+        models = replicate(model, min(chains, len(mine)))
+
     avg_wers = []
     for repeat in range(args.repeats):
         records = []
-        for rec in mine:
+        if models is not None:
+            loaded = [data[rec]['process_fn'](data[rec]) for rec in mine]
+            stime = time.time()
+            outs = lib.dynamic_eval_many(args, models, [a for a, _ in loaded], args.seq_len, args.overlap, tokenizer,
+                                         use_tqdm=False, return_device=True)
+            texts = [decoder(o) for o in outs]
+            torch.cuda.synchronize(device)
+            per_rec = (time.time() - stime) / max(1, len(mine))      # chains overlap: only the mean is meaningful
+            for rec, (_, gold_text), out_text in zip(mine, loaded, texts):
+                records.append({'index': rec, 'id': data[rec]['id'], 'hyp': normalize(out_text).lower(), 'gold': gold_text,
+                                'elapsed': per_rec})
+        for rec in (mine if models is None else []):
             if rank == 0:
                 print(f'Processing {rec + 1}/{len(data)}')
                 print('\n-------\n' + data[rec]['id'] + '\n-------\n')

@@ -230,6 +230,10 @@ int dyn_clip_grad_norm(float* grads, int64_t n, float max_norm, float* norm_and_
 int dyn_stitch_accumulate(const float* log_probs, int64_t ld, float* acc, float* count, int64_t pos, int64_t rows, int64_t C,
                           int64_t acc_rows, void* stream);
 int dyn_stitch_finalize(const float* acc, const float* count, float* out, int64_t rows, int64_t C, void* stream);
+/* Same for an accumulator whose coverage has gaps (outer leave-one-out stitching, reference
+ * lcasr/run_within_recording_loo_eval.py:160-181): out[r] = log(acc[row_index[r]] / count[row_index[r]]), row_index int64 on device. */
+int dyn_stitch_finalize_rows(const float* acc, const float* count, const int64_t* row_index, float* out, int64_t rows, int64_t C,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * wav2vec2 encoder pieces (reference wav2vec2/lib.py:20-23 loads HF Wav2Vec2ForCTC; forward at :163,413, backward at

@@ -41,6 +41,15 @@ def test_run_dynamic_eval_full(cuda, tmp_path, capsys):
         assert set(d) >= {"wer", "words", "ins_rate", "del_rate", "sub_rate", "model_output", "gold", "elapsed_times", "args_dict", "repeat"}
         assert len(d["model_output"]) == 3 and d["repeat"] == f"{r}/2"
     assert "overlap: 256\t seq_len: 512\t WER:" in open(tmp_path / "log.txt").read()
+    # several recordings in flight (chains=2): same transcripts as one at a time when the masks do not depend on draw order
+    noaug = ["-c", ckpt, "-seq", "512", "-o", "256", "-ds", "-nv", "-epochs", "1", "-kwargs", "optim_lr=1e-5", "vocab_size=128", "quiet=True",
+             "spec_augment_n_freq_masks=0"]
+    res = {}
+    for chains in (1, 2):
+        sp = str(tmp_path / f"c{chains}.pkl")
+        H.main(lib.apply_args(H.build_parser(), ["-d", "synthetic_small", "-s", sp] + noaug + [f"chains={chains}"]))
+        res[chains] = pickle.load(open(sp.replace(".pkl", "_1.pkl"), "rb"))
+    assert res[1]["model_output"] == res[2]["model_output"] and len(res[2]["elapsed_times"]) == 3
     # -awmc goes through the same harness (reference run_dynamic_eval_full.py:67-68)
     args = lib.apply_args(H.build_parser(), ["-d", "synthetic_small", "-awmc"] + _argv(ckpt, []))
     assert H.main(args) >= 0
@@ -62,3 +71,74 @@ def test_run_cross_dataset_and_whole_concat(cuda, tmp_path, capsys):
     assert "Baseline WER = " in out and "Adapted WER = " in out and "Delta = " in out
     d = pickle.load(open(save2.replace(".pkl", "_1.pkl"), "rb"))
     assert d["adapt_num_records"] == 3 and d["concat_total_frames"] == 1400 + 900 + 1150 and "delta_wer" in d
+
+
+def test_run_seq_eval_outer_windows(cuda, tmp_path, capsys):
+    """reference run_seq_eval.py: outer windows -> eval_fn -> outer stitch.  (1) one outer window covering the recording
+    reproduces run_dynamic_eval_full's transcripts; (2) several outer windows in flight (chains=2) give the same transcripts
+    as one at a time; (3) stdout / -log / pickle layout."""
+    from dynamic_asr_eval_amd import lib, run_dynamic_eval_full as H, run_seq_eval as S
+    ckpt = _ckpt(tmp_path, cuda)
+    common = ["-c", ckpt, "-seq", "512", "-o", "256", "-ds", "-nv", "-epochs", "1", "-kwargs", "optim_lr=1e-5", "vocab_size=128", "quiet=True",
+              "spec_augment_n_freq_masks=0", "min_minutes=0"]
+    full = str(tmp_path / "full.pkl")
+    H.main(lib.apply_args(H.build_parser(), ["-d", "synthetic_small", "-s", full] + common))
+    whole = str(tmp_path / "whole.pkl")
+    S.main(lib.apply_args(S.build_parser(), ["-d", "synthetic_small", "-s", whole, "-nsti_s", "-1"] + common))
+    a = pickle.load(open(full.replace(".pkl", "_1.pkl"), "rb"))
+    b = pickle.load(open(whole.replace(".pkl", "_1.pkl"), "rb"))
+    # run_seq_eval takes test + dev (reference :59-61): the first three are the test split of run_dynamic_eval_full
+    assert len(b["model_output"]) == 5 and b["model_output"][:3] == a["model_output"]
+    outs = {}
+    for chains in (1, 2):
+        path = str(tmp_path / f"outer{chains}.pkl")
+        avg = S.main(lib.apply_args(S.build_parser(), ["-d", "synthetic_small", "-s", path, "-nsti_s", "768", "-nsti_o", "256",
+                                                       "-log", str(tmp_path / "log.txt")] + common + [f"chains={chains}"]))
+        outs[chains] = pickle.load(open(path.replace(".pkl", "_1.pkl"), "rb"))
+        assert avg >= 0
+    assert outs[1]["model_output"] == outs[2]["model_output"] and len(outs[1]["model_output"]) == 5
+    assert set(outs[1]) >= {"wer", "words", "ins_rate", "del_rate", "sub_rate", "model_output", "gold", "args_dict", "repeat"}
+    out = capsys.readouterr().out
+    assert "WER: " in out and "Average WER: " in out
+    assert "overlap: 256\t seq_len: 512\t WER:" in open(tmp_path / "log.txt").read()
+
+
+def test_outer_stitch_matches_host_rule(cuda):
+    """The on-device outer stitch == the reference's host arithmetic (run_seq_eval.py:120-142) on random windows."""
+    import numpy as np
+    from dynamic_asr_eval_amd.run_seq_eval import outer_stitch
+    g = torch.Generator().manual_seed(0)
+    C, overlap = 17, 64
+    wins = [(0, torch.log_softmax(torch.randn(48, C, generator=g), -1), 192), (128, torch.log_softmax(torch.randn(48, C, generator=g), -1), 192),
+            (256, torch.log_softmax(torch.randn(31, C, generator=g), -1), 124)]
+    got = outer_stitch([(k, lp.to(cuda), u) for k, lp, u in wins], overlap, C, cuda).cpu().numpy()
+    total = sum(lp.shape[0] for _, lp, _ in wins)
+    acc = np.zeros((total, C)); cnt = np.zeros((total, C)); pos = 0
+    for k, lp, u in wins:
+        ds = lp.shape[0]; ov = int(overlap / (u / ds))
+        pos -= ov if k != 0 else 0
+        cnt[pos:pos + ds] += 1; acc[pos:pos + ds] += np.exp(lp.numpy().astype(np.float64)); pos += ds
+    keep = cnt.sum(-1) != 0
+    ref = np.log(acc[keep] / cnt[keep])
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-5
+
+
+def test_run_within_recording_loo_eval(cuda, tmp_path, capsys):
+    """reference run_within_recording_loo_eval.py: audio-disjoint leave-one-out inside a recording; short recordings fall
+    back to the windowed baseline; pickle layout of :218-228."""
+    from dynamic_asr_eval_amd import lib, run_within_recording_loo_eval as L
+    ckpt = _ckpt(tmp_path, cuda)
+    save = str(tmp_path / "loo.pkl")
+    args = lib.apply_args(L.build_parser(), ["-d", "synthetic_small", "-s", save, "-loo_s", "512", "-loo_o", "256"] + _argv(ckpt, []))
+    L.main(args)
+    d = pickle.load(open(save.replace(".pkl", "_1.pkl"), "rb"))
+    assert set(d) >= {"loo", "baseline", "model_output", "baseline_model_output", "gold", "per_recording_meta", "dataset", "args_dict", "repeat"}
+    assert [m["mode"] for m in d["per_recording_meta"]] == ["loo"] * 3 and all(m["n_chunks"] >= 3 for m in d["per_recording_meta"])
+    out = capsys.readouterr().out
+    assert "baseline WER" in out and "LOO WER" in out and "audio-disjoint LOO" in out
+    # an outer chunk longer than the recording: fallback == the baseline transcript
+    save2 = str(tmp_path / "loo2.pkl")
+    L.main(lib.apply_args(L.build_parser(), ["-d", "synthetic_small", "-s", save2, "-loo_s", "65536", "-loo_o", "0", "-split", "dev"] + _argv(ckpt, ["chains=2"])))
+    d2 = pickle.load(open(save2.replace(".pkl", "_1.pkl"), "rb"))
+    assert all(m["mode"] == "fallback_windowed_eval" for m in d2["per_recording_meta"])
+    assert d2["model_output"] == d2["baseline_model_output"]

@@ -230,3 +230,13 @@ def test_oracle_model_and_madgrad_are_self_consistent():
     lamb = 0.1 + 1e-6
     exp = torch.tensor([1.0, -2.0]) - lamb * torch.tensor([0.5, 0.25]) / ((lamb * torch.tensor([0.25, 0.0625])).pow(1 / 3) + 1e-6)
     assert torch.allclose(p.detach(), exp, atol=1e-7)
+
+
+def test_loo_disjoint_pairs_rule():
+    """reference run_within_recording_loo_eval.py:116-121: chunk k covers [k, k + len_k); i and j pair up only if disjoint."""
+    from dynamic_asr_eval_amd.run_within_recording_loo_eval import disjoint_pairs
+    keys = [0, 256, 512, 768, 1024]
+    lens = {0: 512, 256: 512, 512: 512, 768: 512, 1024: 376}
+    v = disjoint_pairs(keys, lens)
+    assert v[0] == [512, 768, 1024] and v[256] == [768, 1024] and v[512] == [0, 1024] and v[1024] == [0, 256, 512]
+    assert disjoint_pairs([0, 100], {0: 300, 100: 300}) == {0: [], 100: []}
