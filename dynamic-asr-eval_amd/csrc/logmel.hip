@@ -93,6 +93,32 @@ __global__ __launch_bounds__(TPB) void normalize_transpose_kernel(const float* _
 }
 }  // namespace
 
+// Per-row (mean, unbiased std) normalisation of a [R, T] spectrogram in place or out of place: the renormalisation after
+// the CHiME-6 channel average, reference lcasr/chime6/run.py:66-68  (spec - spec.mean(-1)) / spec.std(-1).
+// One 1024-thread workgroup per row; two passes (mean, then centred sum of squares) so long rows do not cancel.
+namespace {
+__global__ __launch_bounds__(1024) void rownorm_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t T) {
+    __shared__ float red[16];
+    const float* src = x + (int64_t)blockIdx.x * T;
+    float* dst = out + (int64_t)blockIdx.x * T;
+    float s = 0.f;
+    for (int64_t t = threadIdx.x; t < T; t += 1024) s += src[t];
+    const float mean = dyn::block_sum(s, red) / (float)T;
+    float q = 0.f;
+    for (int64_t t = threadIdx.x; t < T; t += 1024) { const float d = src[t] - mean; q += d * d; }
+    const float var = dyn::block_sum(q, red) / (float)(T > 1 ? T - 1 : 1);
+    const float inv = 1.f / sqrtf(var);
+    for (int64_t t = threadIdx.x; t < T; t += 1024) dst[t] = (src[t] - mean) * inv;
+}
+}  // namespace
+
+extern "C" int dyn_rownorm(const float* x, float* out, int64_t R, int64_t T, void* stream) {
+    DYN_REQUIRE(x && out && R >= 0 && T >= 0 && R < (1ll << 31), DYN_E_ARG, "dyn_rownorm: bad arguments");
+    if (R == 0 || T == 0) return DYN_OK;
+    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)R), dim3(1024), 0, (hipStream_t)stream, x, out, T);
+    return dyn::check_launch("dyn_rownorm");
+}
+
 extern "C" int dyn_reflect_pad(const float* x, float* out, int64_t n, int64_t pad, void* stream) {
     DYN_REQUIRE(x && out && n > 1 && pad >= 0 && pad < n, DYN_E_ARG, "dyn_reflect_pad: bad arguments (need pad < n)");
     int64_t g = dyn::cdiv(n + 2 * pad, TPB);

@@ -86,3 +86,77 @@ def get_text_and_audio_synthetic_small(split, seed=99):
 
 
 datasets_functions['synthetic_small'] = get_text_and_audio_synthetic_small
+
+
+# ---- TEDLIUM-shape and CHiME-6-shape adapters: the steps the reference's adapters run before eval_fn,
+# on the device.  Audio is synthetic (no corpora offline); the STM parsing below follows the reference's text handling.
+def proc_stm_lines(lines):
+    """STM lines -> (gold text, keep timings, remove timings); reference lcasr/tedlium/run.py:30-51
+    (`ignore_time_segment_in_scoring` segments are collected for zeroing, " 'x" is glued back, spaces are squeezed)."""
+    import re
+    all_text, timings, remove_timings = "", [], []
+    for line in lines:
+        sline = line.split(' ')
+        if len(sline) < 6:
+            continue
+        start, end = sline[3], sline[4]
+        text = ' '.join(sline[6:])
+        if text == 'ignore_time_segment_in_scoring':
+            remove_timings.append({'start': float(start), 'end': float(end)})
+            continue
+        all_text += text + ' '
+        timings.append({'start': float(start), 'end': float(end)})
+    all_text = re.sub(r" +", r" ", re.sub(r" '([a-z])", r"'\1", all_text.strip()))
+    return all_text, timings, remove_timings
+
+
+def _process_tedlium(rec):
+    """reference lcasr/tedlium/run.py:91-96: processing_chain(audio) then zero_out_spectogram(remove_timings)."""
+    from .frontend import LogMel, zero_out_spectogram
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lm = _FRONTEND.setdefault(dev.index, LogMel(dev))
+    gold, _, remove = proc_stm_lines(rec['stm'])
+    spec = zero_out_spectogram(lm(synthetic_waveform(rec['seconds'], rec['seed'])), remove)
+    from .wer import basic_normalize
+    return spec, basic_normalize(gold).lower()
+
+
+def get_text_and_audio_synthetic_tedlium(split, durations_s=None, seed=777):
+    """Talks of ~15 min (11 in the test split) with an STM whose every 7th segment is ignored in scoring."""
+    assert split in ('test', 'dev')
+    durations_s = durations_s or ([900] * 11 if split == 'test' else [900] * 8)
+    data = []
+    for i, d in enumerate(durations_s):
+        g = torch.Generator().manual_seed(seed + i)
+        stm, t, k = [], 0.0, 0
+        while t < d - 1.0:
+            dur = min(float(torch.empty(1).uniform_(2.0, 15.0, generator=g)), d - t)
+            text = 'ignore_time_segment_in_scoring' if k % 7 == 3 else synthetic_text(max(1, int(dur * 2.5)), seed + 100 * i + k)
+            stm.append(f'talk{i} 1 spk{i} {t:.2f} {t + dur:.2f} <o,f0,male> {text}')
+            t += dur; k += 1
+        data.append({'id': f'synthetic_tedlium_{split}_{i:03d}', 'text': None, 'audio': None, 'stm': stm, 'seconds': d,
+                     'frames': 1 + int(d * 16000) // 160, 'seed': seed + i, 'process_fn': _process_tedlium})
+    return data
+
+
+datasets_functions['synthetic_tedlium'] = get_text_and_audio_synthetic_tedlium
+
+
+def _process_chime6(rec):
+    """reference lcasr/chime6/run.py:46-70,: the channels of one array -> combine_channels (log-mel each, trim to the first /
+    last word, average, renormalise)."""
+    from .frontend import combine_channels
+    dev = torch.device("cuda", torch.cuda.current_device())
+    wavs = [synthetic_waveform(rec['seconds'] - 0.013 * c, rec['seed'] + 31 * c) for c in range(rec['channels'])]
+    return combine_channels(wavs, rec['stime'], rec['etime'], device=dev), rec['text']
+
+
+def get_text_and_audio_synthetic_chime6(split, durations_s=None, seed=606, channels=4):
+    assert split in ('test', 'dev')
+    durations_s = durations_s or ([7200] * 2 if split == 'test' else [3600] * 2)
+    return [{'id': f'synthetic_chime6_{split}_{i:03d}', 'text': synthetic_text(max(1, int(d * 2.0)), seed + i), 'audio': None,
+             'seconds': d, 'channels': channels, 'stime': 1.5, 'etime': d - 2.0, 'frames': int((d - 3.5) * 100), 'seed': seed + i,
+             'process_fn': _process_chime6} for i, d in enumerate(durations_s)]
+
+
+datasets_functions['synthetic_chime6'] = get_text_and_audio_synthetic_chime6

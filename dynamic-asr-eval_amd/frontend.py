@@ -72,3 +72,50 @@ class LogMel:
 def processing_chain(waveform, device="cuda:0"):
     """Same role as upstream `lcasr.utils.audio_tools.processing_chain`: waveform -> normalised log-mel [1, 80, T]."""
     return LogMel(device)(waveform)
+
+
+def total_frames(seconds):
+    """Seconds -> spectrogram frames (upstream `audio_tools.total_frames`; 100 frames / s, DEFINED here as int(s * 100))."""
+    return int(float(seconds) * 100)
+
+
+def zero_out_spectogram(spec, remove_timings):
+    """TEDLIUM `ignore_time_segment_in_scoring` segments are blanked before eval (reference lcasr/tedlium/run.py:91-96 calls
+    the un-vendored `lcasr.eval.utils.zero_out_spectogram`; rule DEFINED here: spec[:, :, frames(start):frames(end)] = 0).
+    spec: CUDA [1, F, T], modified in place by the time-mask kernel (segments travel as kernel arguments)."""
+    import ctypes
+    F, T = spec.shape[-2], spec.shape[-1]
+    if spec.dim() != 3 or spec.shape[0] != 1 or not spec.is_cuda or not spec.is_contiguous():
+        raise ops.DynError("zero_out_spectogram expects a contiguous CUDA [1, F, T] spectrogram")
+    st, wd = [], []
+    for seg in remove_timings:
+        a, b = min(total_frames(seg['start']), T), min(total_frames(seg['end']), T)
+        if b > a:
+            st.append(a); wd.append(b - a)
+    for i in range(0, len(st), 32):
+        a = (ctypes.c_int32 * len(st[i:i + 32]))(*st[i:i + 32])
+        b = (ctypes.c_int32 * len(wd[i:i + 32]))(*wd[i:i + 32])
+        check(load().dyn_specaug_mask_args(spec.data_ptr(), F, T, ctypes.addressof(a), ctypes.addressof(b), len(a), 1, 0.0, 0,
+                                           torch.cuda.current_stream().cuda_stream), "dyn_specaug_mask_args")
+    return spec
+
+
+def combine_channels(waveforms, stime, etime, device="cuda:0"):
+    """CHiME-6 array combination (reference lcasr/chime6/run.py:46-70): every channel -> un-normalised log-mel, right-padded
+    to the longest channel, trimmed to [frames(stime), frames(etime)), averaged over channels, renormalised per bin
+    ((x - mean) / unbiased std over time).  -> CUDA [1, 80, T']"""
+    fe = LogMel(device, normalize=False)
+    n = max(int(torch.as_tensor(w).numel()) for w in waveforms)
+    a, b = total_frames(stime), total_frames(etime)
+    acc = None
+    for w in waveforms:
+        x = torch.as_tensor(w, dtype=torch.float32).reshape(-1)
+        if x.numel() < n:
+            x = torch.nn.functional.pad(x, (0, n - x.numel()))
+        spec = fe(x)[:, :, a:b].contiguous()
+        if acc is None:
+            acc = torch.zeros_like(spec)
+        ops.axpby(spec, acc, a=1.0 / len(waveforms), b=1.0)
+    check(load().dyn_rownorm(acc.data_ptr(), acc.data_ptr(), acc.shape[1], acc.shape[2], torch.cuda.current_stream().cuda_stream),
+          "dyn_rownorm")
+    return acc

@@ -181,6 +181,10 @@ int64_t dyn_logmel_finish_workspace_bytes(int64_t T, int64_t F);
 int dyn_logmel_finish(float* mel, float* out, int64_t T, int64_t F, float eps, int32_t normalize, void* workspace,
                       int64_t workspace_bytes, void* stream);
 
+/* (x - mean_row) / std_row (unbiased) of a [R, T] spectrogram: the renormalisation after the CHiME-6 channel average
+ * (reference lcasr/chime6/run.py:66-68).  In place when out == x. */
+int dyn_rownorm(const float* x, float* out, int64_t R, int64_t T, void* stream);
+
 /* Optional Loop-A augmentations on a device-resident [F, T] window (random draws stay on the host):
  *   dyn_gather_frames  frame_shuffle (reference lcasr/lib.py:81-84): y = x[:, index] (along_time) or x[index, :]
  *   dyn_moments        (sum, mean, unbiased std) of a buffer — spec.std() of add_random_noise (lib.py:379-382)

@@ -29,3 +29,28 @@ def logmel_ref(waveform, eps=1e-6, normalize=True, dtype=torch.float64):
     if normalize:
         lm = (lm - lm.mean(-1, keepdim=True)) / lm.std(-1, keepdim=True)
     return lm.unsqueeze(0)
+
+
+def total_frames(seconds):
+    return int(float(seconds) * 100)
+
+
+def zero_out_spectogram_ref(spec, remove_timings):
+    """reference lcasr/tedlium/run.py:91-96 (rule defined in frontend.py: frames(start):frames(end) set to zero)."""
+    spec = spec.clone()
+    for seg in remove_timings:
+        spec[:, :, total_frames(seg['start']):total_frames(seg['end'])] = 0
+    return spec
+
+
+def combine_channels_ref(waveforms, stime, etime):
+    """reference lcasr/chime6/run.py:46-70 restated with logmel_ref: pad right, un-normalised log-mel per channel, trim,
+    mean over channels, per-bin renormalisation (unbiased std)."""
+    n = max(torch.as_tensor(w).numel() for w in waveforms)
+    specs = []
+    for w in waveforms:
+        x = torch.as_tensor(w).reshape(-1).to(torch.float64)
+        x = torch.nn.functional.pad(x, (0, n - x.numel()))
+        specs.append(logmel_ref(x, normalize=False)[:, :, total_frames(stime):total_frames(etime)])
+    spec = torch.stack(specs, 0).mean(0)
+    return (spec - spec.mean(-1, keepdim=True)) / spec.std(-1, keepdim=True)

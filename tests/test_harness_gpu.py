@@ -142,3 +142,32 @@ def test_run_within_recording_loo_eval(cuda, tmp_path, capsys):
     d2 = pickle.load(open(save2.replace(".pkl", "_1.pkl"), "rb"))
     assert all(m["mode"] == "fallback_windowed_eval" for m in d2["per_recording_meta"])
     assert d2["model_output"] == d2["baseline_model_output"]
+
+
+def test_tedlium_and_chime6_shaped_adapters_through_the_harness(cuda, tmp_path):
+    """process_fn of the TEDLIUM-shape (log-mel + ignored-segment zeroing) and CHiME-6-shape (channel average +
+    renormalisation) adapters feeds eval_fn like the reference adapters do (tedlium/run.py:91-96, chime6/run.py:46-70)."""
+    from dynamic_asr_eval_amd import datasets as D
+    from dynamic_asr_eval_amd.datasets import proc_stm_lines
+    from dynamic_asr_eval_amd.frontend import total_frames
+    rec = D.get_text_and_audio_synthetic_tedlium('test', durations_s=[40.0])[0]
+    spec, gold = rec['process_fn'](rec)
+    assert spec.is_cuda and spec.shape == (1, 80, 4001) and len(gold) > 0 and 'ignore_time' not in gold
+    _, keep, remove = proc_stm_lines(rec['stm'])
+    for seg in remove:
+        a, b = total_frames(seg['start']), min(total_frames(seg['end']), 4001)
+        assert b > a and torch.all(spec[:, :, a:b] == 0)
+    a, b = total_frames(keep[0]['start']), total_frames(keep[0]['end'])
+    assert spec[:, :, a:b].abs().sum() > 0
+    rec = D.get_text_and_audio_synthetic_chime6('dev', durations_s=[12.0], channels=3)[0]
+    spec, gold = rec['process_fn'](rec)
+    assert spec.shape == (1, 80, total_frames(10.0) - total_frames(1.5)) and spec.mean(-1).abs().max() < 1e-4
+    # and through the harness (tiny model): both adapters are registered names
+    from dynamic_asr_eval_amd import lib, run_dynamic_eval_full as H
+    D.datasets_functions['tiny_ted'] = lambda split: D.get_text_and_audio_synthetic_tedlium(split, durations_s=[12.0, 9.0])
+    ckpt = _ckpt(tmp_path, cuda)
+    p = H.build_parser()
+    for act in p._actions:
+        if act.dest == 'dataset':
+            act.choices = list(D.datasets_functions.keys())
+    assert H.main(lib.apply_args(p, ["-d", "tiny_ted"] + _argv(ckpt, []))) >= 0

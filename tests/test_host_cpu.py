@@ -240,3 +240,16 @@ def test_loo_disjoint_pairs_rule():
     v = disjoint_pairs(keys, lens)
     assert v[0] == [512, 768, 1024] and v[256] == [768, 1024] and v[512] == [0, 1024] and v[1024] == [0, 256, 512]
     assert disjoint_pairs([0, 100], {0: 300, 100: 300}) == {0: [], 100: []}
+
+
+def test_stm_parsing_follows_the_reference_rules():
+    """reference lcasr/tedlium/run.py:30-51."""
+    from dynamic_asr_eval_amd.datasets import proc_stm_lines, get_text_and_audio_synthetic_tedlium
+    lines = ["t 1 s 0.00 2.50 <o> hello  world it 's fine", "short line", "t 1 s 2.50 4.00 <o> ignore_time_segment_in_scoring",
+             "t 1 s 4.00 6.25 <o> we 're   back"]
+    text, keep, remove = proc_stm_lines(lines)
+    assert text == "hello world it's fine we're back"
+    assert keep == [{'start': 0.0, 'end': 2.5}, {'start': 4.0, 'end': 6.25}] and remove == [{'start': 2.5, 'end': 4.0}]
+    recs = get_text_and_audio_synthetic_tedlium('test', durations_s=[60.0])
+    _, _, rem = proc_stm_lines(recs[0]['stm'])
+    assert len(rem) >= 1 and recs[0]['frames'] == 6001
