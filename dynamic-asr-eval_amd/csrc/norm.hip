@@ -185,6 +185,75 @@ int launch_bwd(const float* x, const float* gamma, const float* mean, const floa
 
 }  // namespace
 
+// ---- per-channel affine with fixed statistics: BatchRenorm1d in eval mode (the dynamic-eval loop calls model.eval() so the
+// running statistics are never updated, reference lcasr/lib.py:525):  y = (x - mean_c) * rsqrt(var_c + eps) * w_c + b_c
+namespace {
+__global__ __launch_bounds__(256) void chanaffine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ var, const float* __restrict__ w,
+                                                             const float* __restrict__ b, float* __restrict__ y, int64_t rows, int C,
+                                                             float eps) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float m = mean[c], rs = rsqrtf(var[c] + eps), g = w[c], sh = b ? b[c] : 0.f;
+        for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) y[r * C + c] = (x[r * C + c] - m) * rs * g + sh;
+    }
+}
+
+// dx = dy * rs * w (+ dx_beta * dx); per-workgroup partial column sums of dy * xhat and dy, rows visited in a fixed order
+__global__ __launch_bounds__(256) void chanaffine_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ var, const float* __restrict__ w,
+                                                             const float* __restrict__ dy, float* __restrict__ dx, float dx_beta,
+                                                             float* __restrict__ pg, float* __restrict__ pb, int64_t rows, int C,
+                                                             float eps) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float m = mean[c], rs = rsqrtf(var[c] + eps), g = w[c];
+        float ag = 0.f, ab = 0.f;
+        for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+            const float gy = dy[r * C + c];
+            ag += gy * ((x[r * C + c] - m) * rs);
+            ab += gy;
+            const float o = gy * rs * g;
+            dx[r * C + c] = dx_beta != 0.f ? o + dx_beta * dx[r * C + c] : o;
+        }
+        pg[(int64_t)blockIdx.x * C + c] = ag;
+        pb[(int64_t)blockIdx.x * C + c] = ab;
+    }
+}
+inline int chan_blocks(int64_t rows) { return (int)(rows < 1 ? 1 : rows > 512 ? 512 : rows); }
+}  // namespace
+
+extern "C" int dyn_chanaffine_fwd(const float* x, const float* mean, const float* var, const float* weight, const float* bias,
+                                  float* y, int64_t rows, int64_t C, float eps, void* stream) {
+    DYN_REQUIRE(x && mean && var && weight && y && rows >= 0 && C > 0 && C < (1 << 30), DYN_E_ARG, "dyn_chanaffine_fwd: bad arguments");
+    if (rows == 0) return DYN_OK;
+    hipLaunchKernelGGL(chanaffine_fwd_kernel, dim3(chan_blocks(rows)), dim3(256), 0, (hipStream_t)stream, x, mean, var, weight, bias, y,
+                       rows, (int)C, eps);
+    return dyn::check_launch("dyn_chanaffine_fwd");
+}
+
+extern "C" int64_t dyn_chanaffine_bwd_workspace_bytes(int64_t rows, int64_t C) {
+    return (int64_t)2 * chan_blocks(rows) * C * (int64_t)sizeof(float);
+}
+
+extern "C" int dyn_chanaffine_bwd(const float* x, const float* mean, const float* var, const float* weight, const float* dy,
+                                  float* dx, float dx_beta, float* dweight, float* dbias, float wgrad_beta, int64_t rows, int64_t C,
+                                  float eps, void* workspace, int64_t workspace_bytes, void* stream) {
+    DYN_REQUIRE(x && mean && var && weight && dy && dx && rows >= 0 && C > 0 && C < (1 << 30), DYN_E_ARG, "dyn_chanaffine_bwd: bad arguments");
+    if (rows == 0) return DYN_OK;
+    const int nb = chan_blocks(rows);
+    DYN_REQUIRE(workspace && workspace_bytes >= dyn_chanaffine_bwd_workspace_bytes(rows, C), DYN_E_WORKSPACE,
+                "dyn_chanaffine_bwd: workspace too small");
+    float* pg = (float*)workspace;
+    float* pb = pg + (int64_t)nb * C;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(chanaffine_bwd_kernel, dim3(nb), dim3(256), 0, st, x, mean, var, weight, dy, dx, dx_beta, pg, pb, rows, (int)C, eps);
+    if (dweight && dbias) dyn::launch_reduce_partials_pair(pg, dweight, pb, dbias, (int64_t)nb, C, wgrad_beta, st);
+    else {
+        if (dweight) dyn::launch_reduce_partials(pg, dweight, (int64_t)nb, C, wgrad_beta, st);
+        if (dbias) dyn::launch_reduce_partials(pb, dbias, (int64_t)nb, C, wgrad_beta, st);
+    }
+    return dyn::check_launch("dyn_chanaffine_bwd");
+}
+
 extern "C" int64_t dyn_norm_bwd_workspace_bytes(int64_t rows, int64_t C) {
     return (int64_t)2 * bwd_blocks(rows) * C * (int64_t)sizeof(float);
 }

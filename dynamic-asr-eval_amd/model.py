@@ -352,13 +352,16 @@ class SCConformerXL:
         if kind == "layer_norm":
             y, mean, rstd = ops.layernorm(c, P[p + ".cnorm.weight"], P[p + ".cnorm.bias"], cfg["norm_eps"])
             return y, (mean, rstd)
-        raise ops.DynError("conv_norm='batch_renorm' is not available on the HIP path yet")
+        # batch_renorm, eval mode (the loop calls model.eval(), reference lib.py:525): running statistics are constants
+        y = ops.chanaffine(c, self.buffers[p + ".cnorm.running_mean"], self.buffers[p + ".cnorm.running_var"],
+                           P[p + ".cnorm.weight"], P[p + ".cnorm.bias"], cfg["norm_eps"])
+        return y, (None, None)
 
     def _conv_fwd(self, h, p, lc):
         cfg, P = self.config, self.P
         n, mean, rstd = ops.layernorm(h, P[p + ".norm.weight"], P[p + ".norm.bias"], cfg["norm_eps"])
         u = ops.linear(n, P[p + ".pw1.weight"], P[p + ".pw1.bias"])
-        if cfg["conv_kernel_size"] == 9 and cfg["d_model"] <= 1024 and self.fused_convmod:
+        if cfg["conv_kernel_size"] == 9 and cfg["d_model"] <= 1024 and self.fused_convmod and cfg["conv_norm"] != "batch_renorm":
             ln = cfg["conv_norm"] == "layer_norm"
             s, g, c, nn_, cmean, crstd = ops.convmod_fwd(u, P[p + ".dw.weight"], P[p + ".dw.bias"], P[p + ".cnorm.weight"],
                                                          P[p + ".cnorm.bias"] if ln else None, ln, cfg["norm_eps"], lc is not None)
@@ -518,6 +521,9 @@ class SCConformerXL:
         dc = torch.empty_like(c)
         if cfg["conv_norm"] == "rms_norm":
             ops.rmsnorm_bwd(c, P[p + ".cnorm.weight"], stats[1], dnn, dc, G[p + ".cnorm.weight"], dx_beta=0.0)
+        elif cfg["conv_norm"] == "batch_renorm":
+            ops.chanaffine_bwd(c, self.buffers[p + ".cnorm.running_mean"], self.buffers[p + ".cnorm.running_var"],
+                               P[p + ".cnorm.weight"], dnn, dc, G[p + ".cnorm.weight"], G[p + ".cnorm.bias"], cfg["norm_eps"])
         else:
             ops.layernorm_bwd(c, P[p + ".cnorm.weight"], stats[0], stats[1], dnn, dc, G[p + ".cnorm.weight"],
                               G[p + ".cnorm.bias"], dx_beta=0.0)

@@ -320,6 +320,26 @@ def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, dx_beta=0.0, wgra
     return dx
 
 
+def chanaffine(x, mean, var, weight, bias, eps=1e-5, out=None):
+    """BatchRenorm1d in eval mode: (x - mean_c) * rsqrt(var_c + eps) * weight_c + bias_c over the last dim."""
+    _c(x, "chanaffine.x")
+    C = x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    check(_L().dyn_chanaffine_fwd(x.data_ptr(), mean.data_ptr(), var.data_ptr(), weight.data_ptr(), _opt(bias, "bias") if bias is not None else 0,
+                                  out.data_ptr(), x.numel() // C, C, eps, _stream()), "dyn_chanaffine_fwd")
+    return out
+
+
+def chanaffine_bwd(x, mean, var, weight, dy, dx, dweight, dbias, eps=1e-5, dx_beta=0.0, wgrad_beta=1.0):
+    _c(x, "chanaffine_bwd.x"); _c(dy, "chanaffine_bwd.dy"); _c(dx, "chanaffine_bwd.dx")
+    C = x.shape[-1]
+    ws = workspace(x.device)
+    check(_L().dyn_chanaffine_bwd(x.data_ptr(), mean.data_ptr(), var.data_ptr(), weight.data_ptr(), dy.data_ptr(), dx.data_ptr(), dx_beta,
+                                  0 if dweight is None else dweight.data_ptr(), 0 if dbias is None else dbias.data_ptr(), wgrad_beta,
+                                  x.numel() // C, C, eps, ws.data_ptr(), ws.numel(), _stream()), "dyn_chanaffine_bwd")
+    return dx
+
+
 def rmsnorm(x, gamma, eps=1e-5, out=None):
     _cc(x, "rmsnorm.x"); _cc(gamma, "rmsnorm.gamma")
     C = x.shape[-1]

@@ -99,6 +99,15 @@ int dyn_rmsnorm_fwd(const float* x, const float* gamma, float* y, float* rstd, i
 int dyn_rmsnorm_bwd(const float* x, const float* gamma, const float* rstd, const float* dy, float* dx, float dx_beta,
                     float* dgamma, float wgrad_beta, int64_t rows, int64_t C, void* workspace, int64_t workspace_bytes,
                     void* stream);
+/* BatchRenorm1d in eval mode = per-channel affine with the running statistics (the loop calls model.eval(), reference
+ * lcasr/lib.py:525, so they are constants):  y = (x - mean_c) * rsqrt(var_c + eps) * weight_c + bias_c;  x, y [rows, C].
+ * bwd: dx = dy * rsqrt(var + eps) * weight (+ dx_beta * dx), dweight += sum_r dy * xhat, dbias += sum_r dy (deterministic). */
+int dyn_chanaffine_fwd(const float* x, const float* mean, const float* var, const float* weight, const float* bias, float* y,
+                       int64_t rows, int64_t C, float eps, void* stream);
+int64_t dyn_chanaffine_bwd_workspace_bytes(int64_t rows, int64_t C);
+int dyn_chanaffine_bwd(const float* x, const float* mean, const float* var, const float* weight, const float* dy, float* dx,
+                       float dx_beta, float* dweight, float* dbias, float wgrad_beta, int64_t rows, int64_t C, float eps,
+                       void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Row softmax / log-softmax (row length L <= 16384 fwd, <= 8192 bwd).  softmax_bwd: dx = y*(dy - sum(dy*y))*scale;
  * log_softmax_bwd: dx = dy - exp(y)*sum(dy).  F.log_softmax call sites: reference wav2vec2/lib.py:169,417. */

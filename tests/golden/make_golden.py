@@ -33,6 +33,58 @@ def reference_prepare_chunks():
     return ns["prepare_chunks"]
 
 
+def kernel_fixtures():
+    """Vectors from the ops the reference itself calls (torch CPU), so the HIP kernels are pinned to committed numbers:
+      ctc_64x10x129.npz   torch.nn.CTCLoss(blank=128, reduction='sum') loss + gradient w.r.t. log-probs (reference lcasr/lib.py:492,575,579)
+      adam_3step.npz      torch.optim.Adam trajectory (reference nvidia_ctc/lib.py:43,155-160)
+      madgrad_3step.npz   oracle/madgrad_ref.py trajectory (MADGRAD is un-vendored: parity unpinned, drift guard only)
+      dyneval_trace.npz   2-layer model, 1100-frame recording, 512/256 windows: the whole dynamic-eval loop by the oracle with the
+                          SpecAugment masks stored (RNG does not enter parity): stitched log-probs, argmax ids, adapted-parameter checksum."""
+    g = torch.Generator().manual_seed(4242)
+    T, B, C, S = 64, 2, 129, 10
+    lp = torch.log_softmax(torch.randn(T, B, C, generator=g), -1).requires_grad_(True)
+    tg = torch.randint(0, 128, (B, S), generator=g)
+    tg[0, 3] = tg[0, 2]                                   # a repeated label (needs the blank between)
+    il, tl = torch.tensor([T, T - 9]), torch.tensor([S, S - 3])
+    loss = torch.nn.CTCLoss(blank=128, reduction='sum')(lp, tg, il, tl)
+    loss.backward()
+    np.savez(os.path.join(HERE, "ctc_64x10x129.npz"), log_probs=lp.detach().numpy(), targets=tg.numpy().astype(np.int32),
+             input_lengths=il.numpy().astype(np.int32), target_lengths=tl.numpy().astype(np.int32), loss=float(loss), grad=lp.grad.numpy())
+
+    p0 = torch.randn(1000, generator=g)
+    grads = [torch.randn(1000, generator=g) * (0.5 + k) for k in range(3)]
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p], lr=1e-3)
+    traj = []
+    for gr in grads:
+        p.grad = gr.clone(); opt.step(); traj.append(p.detach().clone().numpy())
+    np.savez(os.path.join(HERE, "adam_3step.npz"), p0=p0.numpy(), grads=np.stack([x.numpy() for x in grads]), params=np.stack(traj), lr=1e-3)
+    from oracle.madgrad_ref import MADGRAD
+    p = torch.nn.Parameter(p0.clone())
+    opt = MADGRAD([p], lr=1e-2)
+    traj = []
+    for gr in grads:
+        p.grad = gr.clone(); opt.step(); traj.append(p.detach().clone().numpy())
+    np.savez(os.path.join(HERE, "madgrad_3step.npz"), p0=p0.numpy(), grads=np.stack([x.numpy() for x in grads]), params=np.stack(traj), lr=1e-2)
+
+    from oracle import dynamic_eval_ref as R
+    from oracle.conformer_ref import SCConformerXLRef
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    cfg = dict(n_layers=2, d_model=256, n_heads=2, head_dim=128, subsampling_conv_channels=64)
+    ref = SCConformerXLRef(cfg, vocab_size=128, seed=5, blank_bias=1.5)
+    spec = torch.randn(1, 80, 1100, generator=g)
+    _, keys = R.prepare_chunks(spec, 512, 256)
+    mg = torch.Generator().manual_seed(7)
+    masks = {k: (R.draw_masks(3, 12, 80, mg), ([], [])) for k in keys}
+    out, params = R.dynamic_eval_ref(ref, spec, 512, 256, SyntheticTokenizer(128), MADGRAD, {'lr': 1e-4}, {}, epochs=1, shuffle=False,
+                                     online=False, fixed_masks=masks, return_params=True)
+    np.savez(os.path.join(HERE, "dyneval_trace.npz"), spec=spec.numpy(), keys=np.array(keys),
+             mask_starts=np.array([masks[k][0][0] for k in keys]), mask_widths=np.array([masks[k][0][1] for k in keys]),
+             logits=out, argmax=out.argmax(-1).astype(np.int32),
+             param_checksum=np.array([float(sum(p.double().sum() for p in params)), float(sum(p.double().abs().sum() for p in params))]),
+             model_seed=5, blank_bias=1.5, lr=1e-4)
+
+
 def main():
     pc = reference_prepare_chunks()
     cases = []
@@ -54,6 +106,7 @@ def main():
     D = sqdist(a, b)
     val, grad = softdtw_forward_backward(D, 1.0, 0.0)
     np.savez(os.path.join(HERE, "softdtw_17x15x2.npz"), a=a, b=b, D=D, gamma=1.0, value=val, grad=grad)
+    kernel_fixtures()
     print("golden fixtures written")
 
 

@@ -259,3 +259,46 @@ def test_chains_and_graphs_are_bit_identical_to_the_sequential_eager_loop(cuda):
     # the adaptation did something: the no-adapt pass differs
     plain = lib.dynamic_eval(_args(epochs=0, quiet=True), hip, specs[0], seq_len, overlap, tok, use_tqdm=False)
     assert np.abs(plain - eager[0]).max() > 1e-6
+
+
+def test_batch_renorm_eval_mode_parity(cuda):
+    """conv_norm='batch_renorm': the loop runs the model in eval mode (reference lib.py:525), i.e. a per-channel affine
+    with the checkpoint's running statistics.  Non-trivial statistics, forward + every parameter gradient vs the oracle,
+    and one adapted dynamic-eval pass."""
+    from oracle import dynamic_eval_ref as R
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    from oracle.conformer_ref import SCConformerXLRef
+    from dynamic_asr_eval_amd.model import SCConformerXL
+    cfg = dict(SMALL, conv_norm="batch_renorm")
+    ref = SCConformerXLRef(cfg, vocab_size=128, seed=13, blank_bias=1.5)
+    g = torch.Generator().manual_seed(2)
+    for name, buf in ref.named_buffers():
+        if name.endswith("running_mean"):
+            buf.copy_(0.3 * torch.randn(buf.shape, generator=g))
+        if name.endswith("running_var"):
+            buf.copy_(0.5 + torch.rand(buf.shape, generator=g))
+    ref.eval()
+    hip = SCConformerXL(cfg, vocab_size=128, device=cuda)
+    hip.load_state_dict(ref.state_dict())
+    x = torch.randn(2, 80, 200, generator=g)
+    out_ref = ref(audio_signal=x)['final_posteriors']
+    out = hip(audio_signal=x.to(cuda))['final_posteriors']
+    assert (out.cpu() - out_ref).abs().max().item() < 2e-4
+    assert torch.equal(out.cpu().argmax(-1), out_ref.argmax(-1))
+    gp = torch.randn(out_ref.shape, generator=g) / out_ref.numel()
+    out_ref.backward(gp)
+    hip.zero_grad(); hip.backward(gp.to(cuda))
+    for (n, p), gh in zip(ref.named_parameters(), hip.grads()):
+        rel = (gh.cpu() - p.grad).abs().max().item() / (p.grad.abs().max().item() + 1e-12)
+        assert rel < 2e-3, f"grad {n}: rel err {rel}"
+    ref.zero_grad()
+    tok = SyntheticTokenizer(128)
+    spec = torch.randn(1, 80, 1100, generator=g)
+    _, keys = R.prepare_chunks(spec, 512, 256)
+    masks = _masks_for(keys, 80, None, seed=4)
+    o_ref = R.dynamic_eval_ref(ref, spec, 512, 256, tok, MADGRAD_REF, {'lr': 1e-4}, {}, epochs=1, shuffle=False, fixed_masks=masks)
+    o = lib.dynamic_eval(_args(optim_lr=1e-4, epochs=1, shuffle=False, spec_augment_fixed_masks=masks, quiet=True), hip, spec, 512, 256, tok,
+                         use_tqdm=False)
+    assert np.abs(o - o_ref).max() < 1e-3 and np.array_equal(o.argmax(-1), o_ref.argmax(-1))
