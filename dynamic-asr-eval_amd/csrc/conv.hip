@@ -221,6 +221,221 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_fwd_kernel(const float* __res
     }
 }
 
+
+// ---- vectorised subsampling forwards (C % 4 == 0): one wave per output row (b, to), lane = 4 consecutive channels, so every
+// access is a 16-B-per-lane transaction (1 KiB per wave-instruction), and the 3-column window slides along f: each input
+// element is loaded (and SiLU'd) once per output row instead of up to 3 times.  Accumulation order per output is the same
+// (dt major, df minor) as the scalar kernels, so results are bit-identical to them.
+__device__ __forceinline__ float4 silu4(float4 v) { return make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w)); }
+__device__ __forceinline__ void fma4(float4& a, const float4& w, const float4& v) {
+    a.x += w.x * v.x; a.y += w.y * v.y; a.z += w.z * v.z; a.w += w.w * v.w;
+}
+__device__ __forceinline__ void load_w4(const float* __restrict__ w, int c0, float4 (&wk)[9]) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) wk[j] = make_float4(w[(c0 + 0) * 9 + j], w[(c0 + 1) * 9 + j], w[(c0 + 2) * 9 + j], w[(c0 + 3) * 9 + j]);
+}
+
+__global__ __launch_bounds__(256) void dwconv2d_s2_fwd_v4_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, float* __restrict__ u,
+                                                                  int64_t T, int F, int64_t To, int Fo, int C, int64_t rows) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wv;     // (b, to) flattened
+    if (row >= rows) return;
+    const int64_t b = row / To, to = row % To;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c0 = lane * 4; c0 < C; c0 += 256) {
+        float4 wk[9];
+        load_w4(w, c0, wk);
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+        const float* zr[3];
+        bool ok[3];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int64_t t = 2 * to + dt - 1;
+            ok[dt] = t >= 0 && t < T;
+            zr[dt] = z + ((b * T + (ok[dt] ? t : 0)) * F) * C + c0;
+        }
+        float4 prev[3] = {zero, zero, zero};      // column 2*fo - 1 (f = -1 for fo = 0: padding)
+        float* ur = u + (row * Fo) * C + c0;
+        for (int fo = 0; fo < Fo; ++fo) {
+            const int f0 = 2 * fo, f1 = 2 * fo + 1;
+            float4 c0v[3], c1v[3];
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                c0v[dt] = ok[dt] ? silu4(*reinterpret_cast<const float4*>(zr[dt] + (int64_t)f0 * C)) : zero;
+                c1v[dt] = (ok[dt] && f1 < F) ? silu4(*reinterpret_cast<const float4*>(zr[dt] + (int64_t)f1 * C)) : zero;
+            }
+            float4 acc = bv;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                // skipped taps of the scalar kernel are exact zeros here: adding w * 0 leaves the sum unchanged
+                fma4(acc, wk[dt * 3 + 0], prev[dt]);
+                fma4(acc, wk[dt * 3 + 1], c0v[dt]);
+                fma4(acc, wk[dt * 3 + 2], c1v[dt]);
+                prev[dt] = c1v[dt];
+            }
+            *reinterpret_cast<float4*>(ur + (int64_t)fo * C) = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv2d_first_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ bias, float* __restrict__ z,
+                                                                   int64_t T, int F, int64_t To, int Fo, int C, int64_t rows) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    if (row >= rows) return;
+    const int64_t b = row / To, to = row % To;
+    for (int c0 = lane * 4; c0 < C; c0 += 256) {
+        float4 wk[9];
+        load_w4(w, c0, wk);
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+        const float* xr[3];
+        bool ok[3];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int64_t t = 2 * to + dt - 1;
+            ok[dt] = t >= 0 && t < T;
+            xr[dt] = x + (b * T + (ok[dt] ? t : 0)) * F;
+        }
+        float prev[3] = {0.f, 0.f, 0.f};
+        float* zr = z + (row * Fo) * C + c0;
+        for (int fo = 0; fo < Fo; ++fo) {
+            const int f0 = 2 * fo, f1 = 2 * fo + 1;
+            float4 acc = bv;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                const float a0 = ok[dt] ? xr[dt][f0] : 0.f;                 // wave-uniform loads
+                const float a1 = (ok[dt] && f1 < F) ? xr[dt][f1] : 0.f;
+                const float p = prev[dt];
+                acc.x += wk[dt * 3 + 0].x * p; acc.y += wk[dt * 3 + 0].y * p; acc.z += wk[dt * 3 + 0].z * p; acc.w += wk[dt * 3 + 0].w * p;
+                acc.x += wk[dt * 3 + 1].x * a0; acc.y += wk[dt * 3 + 1].y * a0; acc.z += wk[dt * 3 + 1].z * a0; acc.w += wk[dt * 3 + 1].w * a0;
+                acc.x += wk[dt * 3 + 2].x * a1; acc.y += wk[dt * 3 + 2].y * a1; acc.z += wk[dt * 3 + 2].z * a1; acc.w += wk[dt * 3 + 2].w * a1;
+                prev[dt] = a1;
+            }
+            *reinterpret_cast<float4*>(zr + (int64_t)fo * C) = acc;
+        }
+    }
+}
+
+
+// ---- vectorised subsampling backwards (C % 4 == 0): same wave-per-row / lane = 4 channels scheme as the forwards ----
+__device__ __forceinline__ float4 silu_grad4(float4 v) { return make_float4(silu_grad(v.x), silu_grad(v.y), silu_grad(v.z), silu_grad(v.w)); }
+
+// dz row (b, t): every input element gathers the 1, 2 or 4 outputs it fed (parity of t and f decides which taps exist).
+__global__ __launch_bounds__(256) void dwconv2d_s2_dgrad_v4_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                                                    const float* __restrict__ du, float* __restrict__ dz,
+                                                                    int64_t T, int F, int64_t To, int Fo, int C, int64_t rows) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wv;     // (b, t) flattened
+    if (row >= rows) return;
+    const int64_t b = row / T, t = row % T;
+    for (int c0 = lane * 4; c0 < C; c0 += 256) {
+        float4 wk[9];
+        load_w4(w, c0, wk);
+        const float* zr = z + (row * F) * C + c0;
+        float* dr = dz + (row * F) * C + c0;
+        const float* gb = du + (b * To * Fo) * C + c0;
+        for (int f = 0; f < F; ++f) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                const int64_t tt = t + 1 - dt;  // = 2 * to
+                if (tt < 0 || (tt & 1)) continue;
+                const int64_t to = tt >> 1;
+                if (to >= To) continue;
+#pragma unroll
+                for (int df = 0; df < 3; ++df) {
+                    const int ff = f + 1 - df;
+                    if (ff < 0 || (ff & 1)) continue;
+                    const int fo = ff >> 1;
+                    if (fo >= Fo) continue;
+                    fma4(acc, wk[dt * 3 + df], *reinterpret_cast<const float4*>(gb + (to * Fo + fo) * C));
+                }
+            }
+            const float4 sg = silu_grad4(*reinterpret_cast<const float4*>(zr + (int64_t)f * C));
+            *reinterpret_cast<float4*>(dr + (int64_t)f * C) = make_float4(acc.x * sg.x, acc.y * sg.y, acc.z * sg.z, acc.w * sg.w);
+        }
+    }
+}
+
+// weight gradient partials: one wave per tile of `per` output rows, sliding 3-column window like the forward; the four
+// waves of a workgroup are summed in wave order through LDS, so one partial row per WORKGROUP reaches the reducer.
+template <bool FIRST>   // FIRST: the 1-channel first conv (input x [B, T, F], no activation); else depthwise with SiLU(z)
+__global__ __launch_bounds__(256) void conv2d_s2_wgrad_v4_kernel(const float* __restrict__ in, const float* __restrict__ g_out,
+                                                                  float* __restrict__ partial_w, float* __restrict__ partial_b,
+                                                                  int64_t T, int F, int64_t To, int Fo, int C, int64_t per,
+                                                                  int64_t chunks, int64_t tiles) {
+    __shared__ float4 red[3][64][10];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;     // (b, chunk) flattened
+    const bool live = tile < tiles;
+    const int64_t b = live ? tile / chunks : 0, to0 = live ? (tile % chunks) * per : 0;
+    const int64_t to1 = live ? ((to0 + per < To) ? to0 + per : To) : 0;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int cb = 0; cb < C; cb += 256) {
+        const int c0 = cb + lane * 4;
+        const bool cok = c0 < C;
+        float4 acc[9], accb = zero;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[j] = zero;
+        for (int64_t to = to0; to < to1 && cok; ++to) {
+            const float* ir[3];
+            bool ok[3];
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                const int64_t t = 2 * to + dt - 1;
+                ok[dt] = t >= 0 && t < T;
+                ir[dt] = FIRST ? in + (b * T + (ok[dt] ? t : 0)) * F : in + ((b * T + (ok[dt] ? t : 0)) * F) * C + c0;
+            }
+            const float* gr = g_out + ((b * To + to) * Fo) * C + c0;
+            float4 prev[3] = {zero, zero, zero};
+            for (int fo = 0; fo < Fo; ++fo) {
+                const int f0 = 2 * fo, f1 = 2 * fo + 1;
+                const float4 g = *reinterpret_cast<const float4*>(gr + (int64_t)fo * C);
+                accb.x += g.x; accb.y += g.y; accb.z += g.z; accb.w += g.w;
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
+                    float4 a0 = zero, a1 = zero;
+                    if (FIRST) {
+                        if (ok[dt]) { const float v = ir[dt][f0]; a0 = make_float4(v, v, v, v); }
+                        if (ok[dt] && f1 < F) { const float v = ir[dt][f1]; a1 = make_float4(v, v, v, v); }
+                    } else {
+                        if (ok[dt]) a0 = silu4(*reinterpret_cast<const float4*>(ir[dt] + (int64_t)f0 * C));
+                        if (ok[dt] && f1 < F) a1 = silu4(*reinterpret_cast<const float4*>(ir[dt] + (int64_t)f1 * C));
+                    }
+                    fma4(acc[dt * 3 + 0], g, prev[dt]);
+                    fma4(acc[dt * 3 + 1], g, a0);
+                    fma4(acc[dt * 3 + 2], g, a1);
+                    prev[dt] = a1;
+                }
+            }
+        }
+        __syncthreads();
+        if (wv > 0) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) red[wv - 1][lane][j] = acc[j];
+            red[wv - 1][lane][9] = accb;
+        }
+        __syncthreads();
+        if (wv == 0 && cok) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { const float4 v = red[k][lane][j]; acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w; }
+                const float4 v = red[k][lane][9];
+                accb.x += v.x; accb.y += v.y; accb.z += v.z; accb.w += v.w;
+            }
+            // partial rows are tap-major ([workgroup][j][C]): every store is a coalesced 16 B per lane; the reducer
+            // (reduce_partials_2d_taps_kernel) writes the [C][3][3] weight-gradient layout
+            const int64_t prow = blockIdx.x;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) *reinterpret_cast<float4*>(partial_w + (prow * 9 + j) * C + c0) = acc[j];
+            *reinterpret_cast<float4*>(partial_b + prow * C + c0) = accb;
+        }
+    }
+}
+
 // dz[b,t,f,c] = silu'(z) * sum_{(to,dt),(fo,df): 2to+dt-1=t, 2fo+df-1=f} w[c,dt,df] * du[b,to,fo,c]
 __global__ __launch_bounds__(256) void dwconv2d_s2_dgrad_kernel(const float* __restrict__ z, const float* __restrict__ w,
                                                                  const float* __restrict__ du, float* __restrict__ dz,
@@ -317,6 +532,14 @@ inline int64_t wgrad_tiles(int64_t B, int64_t T, int64_t* per_block) {
     return chunks;
 }
 
+// 2-D subsampling weight gradients: one wave per tile, enough tiles (up to 4096 per sample) to fill the chip at B = 1.
+inline int64_t wgrad_tiles2d(int64_t To, int64_t* per_block) {
+    int64_t chunks = To < 4096 ? To : 4096;
+    if (chunks < 1) chunks = 1;
+    *per_block = dyn::cdiv(To > 0 ? To : 1, chunks);
+    return dyn::cdiv(To > 0 ? To : 1, *per_block);
+}
+
 }  // namespace
 
 extern "C" int dyn_dwconv1d_fwd(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t T, int64_t C,
@@ -368,6 +591,12 @@ extern "C" int dyn_conv2d_first_fwd(const float* x, const float* w, const float*
     DYN_REQUIRE(x && w && bias && z && B >= 0 && T > 0 && F > 0 && C > 0, DYN_E_ARG, "dyn_conv2d_first_fwd: bad arguments");
     if (B == 0) return DYN_OK;
     const int64_t To = (T - 1) / 2 + 1, Fo = (F - 1) / 2 + 1;
+    if (C % 4 == 0 && (((uintptr_t)z | (uintptr_t)bias) & 15) == 0) {
+        const int64_t rows = B * To;
+        hipLaunchKernelGGL(conv2d_first_fwd_v4_kernel, dim3((unsigned)dyn::cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, z,
+                           T, (int)F, To, (int)Fo, (int)C, rows);
+        return dyn::check_launch("dyn_conv2d_first_fwd");
+    }
     dim3 grid((unsigned)To, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
     hipLaunchKernelGGL(conv2d_first_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, z, T, (int)F, To, (int)Fo, (int)C);
     return dyn::check_launch("dyn_conv2d_first_fwd");
@@ -387,7 +616,7 @@ extern "C" int dyn_conv2d_first_dgrad(const float* dz, const float* w, float* dx
 
 extern "C" int64_t dyn_conv2d_wgrad_workspace_bytes(int64_t B, int64_t To, int64_t C) {
     int64_t per;
-    const int64_t tiles = wgrad_tiles(B, To, &per) * B;
+    const int64_t tiles = wgrad_tiles2d(To, &per) * B;
     return tiles * C * 10 * (int64_t)sizeof(float);
 }
 
@@ -397,14 +626,22 @@ extern "C" int dyn_conv2d_first_wgrad(const float* x, const float* dz, float* dw
     if (B == 0) return DYN_OK;
     const int64_t To = (T - 1) / 2 + 1, Fo = (F - 1) / 2 + 1;
     int64_t per;
-    const int64_t chunks = wgrad_tiles(B, To, &per), tiles = chunks * B;
+    const int64_t chunks = wgrad_tiles2d(To, &per), tiles = chunks * B;
     DYN_REQUIRE(workspace && workspace_bytes >= tiles * C * 10 * (int64_t)sizeof(float), DYN_E_WORKSPACE,
                 "dyn_conv2d_first_wgrad: workspace too small");
     float* pw = (float*)workspace;
     float* pb = pw + tiles * C * 9;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)chunks, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
-    hipLaunchKernelGGL(conv2d_first_wgrad_kernel, grid, dim3(256), 0, st, x, dz, pw, pb, T, (int)F, To, (int)Fo, (int)C, per);
+    if (C % 4 == 0 && (((uintptr_t)dz) & 15) == 0) {
+        hipLaunchKernelGGL((conv2d_s2_wgrad_v4_kernel<true>), dim3((unsigned)dyn::cdiv(tiles, 4)), dim3(256), 0, st, x, dz, pw, pb, T, (int)F,
+                           To, (int)Fo, (int)C, per, chunks, tiles);
+        dyn::launch_reduce_partials_taps(pw, dw, dyn::cdiv(tiles, 4), C * 9, beta, (int)C, st);
+        dyn::launch_reduce_partials(pb, dbias, dyn::cdiv(tiles, 4), C, beta, st);
+        return dyn::check_launch("dyn_conv2d_first_wgrad");
+    } else {
+        dim3 grid((unsigned)chunks, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
+        hipLaunchKernelGGL(conv2d_first_wgrad_kernel, grid, dim3(256), 0, st, x, dz, pw, pb, T, (int)F, To, (int)Fo, (int)C, per);
+    }
     dyn::launch_reduce_partials(pw, dw, tiles, C * 9, beta, st);
     dyn::launch_reduce_partials(pb, dbias, tiles, C, beta, st);
     return dyn::check_launch("dyn_conv2d_first_wgrad");
@@ -415,6 +652,12 @@ extern "C" int dyn_dwconv2d_s2_fwd(const float* z, const float* w, const float* 
     DYN_REQUIRE(z && w && bias && u && B >= 0 && T > 0 && F > 0 && C > 0, DYN_E_ARG, "dyn_dwconv2d_s2_fwd: bad arguments");
     if (B == 0) return DYN_OK;
     const int64_t To = (T - 1) / 2 + 1, Fo = (F - 1) / 2 + 1;
+    if (C % 4 == 0 && (((uintptr_t)z | (uintptr_t)u | (uintptr_t)bias) & 15) == 0) {
+        const int64_t rows = B * To;
+        hipLaunchKernelGGL(dwconv2d_s2_fwd_v4_kernel, dim3((unsigned)dyn::cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, z, w, bias, u,
+                           T, (int)F, To, (int)Fo, (int)C, rows);
+        return dyn::check_launch("dyn_dwconv2d_s2_fwd");
+    }
     dim3 grid((unsigned)To, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
     hipLaunchKernelGGL(dwconv2d_s2_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, w, bias, u, T, (int)F, To, (int)Fo, (int)C);
     return dyn::check_launch("dyn_dwconv2d_s2_fwd");
@@ -425,6 +668,12 @@ extern "C" int dyn_dwconv2d_s2_dgrad(const float* z, const float* w, const float
     DYN_REQUIRE(z && w && du && dz && B >= 0 && T > 0 && F > 0 && C > 0, DYN_E_ARG, "dyn_dwconv2d_s2_dgrad: bad arguments");
     if (B == 0) return DYN_OK;
     const int64_t To = (T - 1) / 2 + 1, Fo = (F - 1) / 2 + 1;
+    if (C % 4 == 0 && ((((uintptr_t)z) | ((uintptr_t)du) | ((uintptr_t)dz)) & 15) == 0) {
+        const int64_t rows = B * T;
+        hipLaunchKernelGGL(dwconv2d_s2_dgrad_v4_kernel, dim3((unsigned)dyn::cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, z, w, du, dz,
+                           T, (int)F, To, (int)Fo, (int)C, rows);
+        return dyn::check_launch("dyn_dwconv2d_s2_dgrad");
+    }
     dim3 grid((unsigned)T, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
     hipLaunchKernelGGL(dwconv2d_s2_dgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, w, du, dz, T, (int)F, To, (int)Fo, (int)C);
     return dyn::check_launch("dyn_dwconv2d_s2_dgrad");
@@ -436,14 +685,22 @@ extern "C" int dyn_dwconv2d_s2_wgrad(const float* z, const float* du, float* dw,
     if (B == 0) return DYN_OK;
     const int64_t To = (T - 1) / 2 + 1, Fo = (F - 1) / 2 + 1;
     int64_t per;
-    const int64_t chunks = wgrad_tiles(B, To, &per), tiles = chunks * B;
+    const int64_t chunks = wgrad_tiles2d(To, &per), tiles = chunks * B;
     DYN_REQUIRE(workspace && workspace_bytes >= tiles * C * 10 * (int64_t)sizeof(float), DYN_E_WORKSPACE,
                 "dyn_dwconv2d_s2_wgrad: workspace too small");
     float* pw = (float*)workspace;
     float* pb = pw + tiles * C * 9;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)chunks, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
-    hipLaunchKernelGGL(dwconv2d_s2_wgrad_kernel, grid, dim3(256), 0, st, z, du, pw, pb, T, (int)F, To, (int)Fo, (int)C, per);
+    if (C % 4 == 0 && ((((uintptr_t)z) | ((uintptr_t)du)) & 15) == 0) {
+        hipLaunchKernelGGL((conv2d_s2_wgrad_v4_kernel<false>), dim3((unsigned)dyn::cdiv(tiles, 4)), dim3(256), 0, st, z, du, pw, pb, T, (int)F,
+                           To, (int)Fo, (int)C, per, chunks, tiles);
+        dyn::launch_reduce_partials_taps(pw, dw, dyn::cdiv(tiles, 4), C * 9, beta, (int)C, st);
+        dyn::launch_reduce_partials(pb, dbias, dyn::cdiv(tiles, 4), C, beta, st);
+        return dyn::check_launch("dyn_dwconv2d_s2_wgrad");
+    } else {
+        dim3 grid((unsigned)chunks, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
+        hipLaunchKernelGGL(dwconv2d_s2_wgrad_kernel, grid, dim3(256), 0, st, z, du, pw, pb, T, (int)F, To, (int)Fo, (int)C, per);
+    }
     dyn::launch_reduce_partials(pw, dw, tiles, C * 9, beta, st);
     dyn::launch_reduce_partials(pb, dbias, tiles, C, beta, st);
     return dyn::check_launch("dyn_dwconv2d_s2_wgrad");

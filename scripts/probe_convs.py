@@ -1,0 +1,29 @@
+"""Times the subsampling kernels at the window shapes (B=2: x [2,16384,80] -> z1 [2,8192,40,256] -> u2 [2,4096,20,256])."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dynamic_asr_eval_amd import ops
+dev = torch.device("cuda:0")
+def timeit(fn, n=10):
+    for _ in range(3): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+for B in (2, 1):
+    C = 256
+    x = torch.randn(B, 16384, 80, device=dev)
+    w1 = torch.randn(C, 3, 3, device=dev); b1 = torch.randn(C, device=dev)
+    z1 = ops.conv2d_first(x, w1, b1)
+    u2 = ops.dwconv2d_s2(z1, w1, b1)
+    du2 = torch.randn_like(u2); dz1 = torch.randn_like(z1)
+    dw = torch.zeros(C, 3, 3, device=dev); db = torch.zeros(C, device=dev)
+    GB = lambda *ts: sum(t.numel() for t in ts) * 4 / 1e9
+    for name, fn, gb in (("conv2d_first fwd", lambda: ops.conv2d_first(x, w1, b1, out=z1), GB(x, z1)),
+                         ("dwconv2d_s2 fwd", lambda: ops.dwconv2d_s2(z1, w1, b1, out=u2), GB(z1, u2)),
+                         ("dwconv2d_s2 dgrad", lambda: ops.dwconv2d_s2_dgrad(z1, w1, du2, out=dz1), GB(z1, du2, dz1)),
+                         ("dwconv2d_s2 wgrad", lambda: ops.dwconv2d_s2_wgrad(z1, du2, dw, db, beta=0.0), GB(z1, du2)),
+                         ("conv2d_first wgrad", lambda: ops.conv2d_first_wgrad(x, dz1, dw, db, beta=0.0), GB(x, dz1))):
+        us = timeit(fn)
+        print(f"B={B} {name:20s} {us:8.1f} us  {gb/us*1e6/1e3:6.2f} TB/s algorithmic ({gb*1e3:.0f} MB)", flush=True)

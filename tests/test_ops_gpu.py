@@ -117,7 +117,7 @@ def test_dwconv1d(cuda, T, C, KW):
     _close(db, br.grad, 3e-4, "dwconv1d bgrad")
 
 
-@pytest.mark.parametrize("T,Fq,C", [(64, 80, 256), (37, 21, 96), (1, 1, 32)])
+@pytest.mark.parametrize("T,Fq,C", [(64, 80, 256), (37, 21, 96), (1, 1, 32), (5, 7, 6), (9, 12, 516)])
 def test_subsampling_convs(cuda, T, Fq, C):
     from dynamic_asr_eval_amd import ops
     B = 2
