@@ -114,6 +114,31 @@ __global__ void colsum_partial_kernel(const float* __restrict__ x, float* __rest
     if (rl == 0 && col < C) partial[(int64_t)blockIdx.y * C + col] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
+// Column sums, 16 B per lane: a wave covers a 256-column strip of a row with one 1-KiB transaction; the four waves of a
+// workgroup split the rows of a chunk and are combined in wave order through LDS; chunk partials go to the fixed-order
+// 2-D reducer.  Thousands of waves instead of C/32 workgroups: bias gradients of [2048..8192, 768..4096] activations.
+__global__ __launch_bounds__(256) void colsum_v4_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t rows,
+                                                                int C, int64_t rows_per_chunk) {
+    __shared__ float4 red[3][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + lane) * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = (r0 + rows_per_chunk < rows) ? r0 + rows_per_chunk : rows;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c0 < C)
+        for (int64_t r = r0 + wv; r < r1; r += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * C + c0);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    if (wv > 0) red[wv - 1][lane] = s;
+    __syncthreads();
+    if (wv == 0 && c0 < C) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const float4 v = red[k][lane]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.y * C + c0) = s;
+    }
+}
+
 // Column sums in ONE launch for the common small case (bias gradients of a 2048..8192-row activation): 1024 threads =
 // 32 columns x 32 row-lanes, one 128-B segment per row per wave half; lanes are combined through LDS in lane order.
 __global__ __launch_bounds__(1024) void colsum_single_kernel(const float* __restrict__ x, float* out, int64_t rows, int C, float beta) {
@@ -239,6 +264,13 @@ extern "C" int dyn_colsum(const float* x, float* out, int64_t rows, int64_t C, f
                 "dyn_colsum: workspace too small");
     const int64_t rpc = dyn::cdiv(rows > 0 ? rows : 1, chunks);
     hipStream_t st = (hipStream_t)stream;
+    if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)workspace) & 15) == 0 && rows >= 256) {
+        const int64_t ch = dyn::cdiv(rows, rpc);
+        hipLaunchKernelGGL(colsum_v4_partial_kernel, dim3((unsigned)dyn::cdiv(C, 256), (unsigned)ch), dim3(256), 0, st, x, (float*)workspace,
+                           rows, (int)C, rpc);
+        dyn::launch_reduce_partials((const float*)workspace, out, ch, C, beta, st);
+        return dyn::check_launch("dyn_colsum");
+    }
     if (rows <= 8192 && C >= 256) {  // enough column strips to occupy the chip: one launch instead of two
         hipLaunchKernelGGL(colsum_single_kernel, dim3((unsigned)dyn::cdiv(C, 32)), dim3(1024), 0, st, x, out, rows, (int)C, beta);
         return dyn::check_launch("dyn_colsum");

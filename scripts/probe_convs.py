@@ -27,3 +27,7 @@ for B in (2, 1):
                          ("conv2d_first wgrad", lambda: ops.conv2d_first_wgrad(x, dz1, dw, db, beta=0.0), GB(x, dz1))):
         us = timeit(fn)
         print(f"B={B} {name:20s} {us:8.1f} us  {gb/us*1e6/1e3:6.2f} TB/s algorithmic ({gb*1e3:.0f} MB)", flush=True)
+for rows, C in ((2048, 768), (2048, 3072), (2048, 4096), (8192, 768)):
+    x = torch.randn(rows, C, device=dev); out = torch.zeros(C, device=dev)
+    us = timeit(lambda: ops.colsum(x, out, beta=1.0), n=50)
+    print(f"colsum [{rows},{C}] {us:7.1f} us  {rows*C*4/us/1e6:6.2f} TB/s", flush=True)
