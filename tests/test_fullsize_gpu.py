@@ -1,0 +1,105 @@
+"""Full-size checks (BASELINE.json configs[1] shapes: SCConformerXL 6 x 768, V+1 = 4096, 16384-frame windows, overlap
+14336) through size-independent properties — the CPU oracle needs ~8 s per such window, so parity at this size is pinned by
+invariants instead: normalised posteriors, exact weight restoration, eager == hipGraph replay == interleaved chains bit for
+bit, stitched length and coverage, the zero-gradient shortcut, and GEMM linearity at the real shapes."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(**kw):
+    a = argparse.Namespace()
+    a.config = {'model': {'subsampling_factor': 8}, 'audio_chunking': {'size': 16384, 'overlap': 0}, 'training': {}}
+    a.__dict__.update(dict(optim_lr=9e-5, epochs=1, shuffle=False, quiet=True, spec_augment_n_freq_masks=6,
+                           spec_augment_freq_mask_param=34, gemm_shared_gpu=1))
+    a.__dict__.update(kw)
+    return a
+
+
+@pytest.fixture(scope="module")
+def xl(cuda):
+    from dynamic_asr_eval_amd.model import SCConformerXL
+    from dynamic_asr_eval_amd.synthetic_weights import init_synthetic
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    m = SCConformerXL(vocab_size=4095, device=cuda)
+    init_synthetic(m, seed=0, blank_bias=1.0)
+    return m, SyntheticTokenizer(4095)
+
+
+def test_full_window_forward_is_a_distribution_and_backward_shortcut_is_exact(cuda, xl):
+    model, _ = xl
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 80, 16384, generator=g).to(cuda)
+    post = model(audio_signal=x)['final_posteriors']
+    assert post.shape == (2, 2048, 4096) and torch.isfinite(post).all()
+    assert (post.exp().sum(-1) - 1).abs().max().item() < 1e-4
+    gp = torch.zeros_like(post)
+    gp[0] = torch.randn(post.shape[1:], generator=g).to(cuda) / post[0].numel()
+    model.zero_grad(); model.backward(gp)
+    full = model.flat_grads.clone()
+    model(audio_signal=x)
+    model.zero_grad(); model.backward(gp[:1].contiguous(), n_active=1)
+    assert torch.isfinite(full).all() and full.abs().max().item() > 0
+    assert (model.flat_grads - full).abs().max().item() / full.abs().max().item() < 1e-5
+
+
+def test_dynamic_eval_full_size_invariants(cuda, xl):
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.model import SCConformerXL
+    model, tok = xl
+    before = model.flat_params.clone()
+    from dynamic_asr_eval_amd.datasets import synthetic_spec
+    spec = synthetic_spec(16384 + 2 * 2048 + 700, seed=3)                 # 3 full windows + one short tail window
+    torch.manual_seed(11)
+    eager = lib.dynamic_eval(_args(use_graphs=False), model, spec, 16384, 14336, tok, use_tqdm=False)
+    assert torch.equal(model.flat_params, before), "weights must be restored bit for bit (reference lib.py:636-637)"
+    # stitched output: one row per 8 input frames over the covered span, every row a distribution
+    # windows at 0, 2048, 4096 and the 15036-frame tail at 6144: 2048-row outputs advance by 256 rows, the tail (1880 rows) lands at
+    # 768 -> 2648 covered rows (reference lib.py:615-629 position rule)
+    assert eager.shape == (2648, 4096)
+    assert np.isfinite(eager).all() and np.abs(np.exp(eager.astype(np.float64)).sum(-1) - 1).max() < 1e-3
+    # adaptation changes the result; epochs = 0 is the plain windowed forward
+    plain = lib.dynamic_eval(_args(epochs=0), model, spec, 16384, 14336, tok, use_tqdm=False)
+    assert plain.shape == eager.shape and np.abs(plain - eager).max() > 1e-6
+    # hipGraph replay and two recordings in flight reproduce the eager sequential numbers exactly (same SpecAugment draws)
+    torch.manual_seed(11)
+    graphed = lib.dynamic_eval(_args(use_graphs=True), model, spec, 16384, 14336, tok, use_tqdm=False)
+    assert np.array_equal(eager, graphed)
+    twin = SCConformerXL(vocab_size=4095, device=cuda)
+    twin.flat_params.copy_(model.flat_params)
+    from oracle.dynamic_eval_ref import draw_masks, prepare_chunks
+    _, keys = prepare_chunks(spec, 16384, 14336)
+    mg = torch.Generator().manual_seed(5)
+    masks = {k: (draw_masks(6, 34, 80, mg), ([], [])) for k in keys}
+    one = lib.dynamic_eval(_args(spec_augment_fixed_masks=masks), model, spec, 16384, 14336, tok, use_tqdm=False)
+    two = lib.dynamic_eval_many(_args(spec_augment_fixed_masks=masks), [model, twin], [spec, spec], 16384, 14336, tok, use_tqdm=False)
+    assert np.array_equal(one, two[0]) and np.array_equal(one, two[1])
+    assert torch.equal(model.flat_params, before) and torch.equal(twin.flat_params, before)
+
+
+@pytest.mark.parametrize("mode,M,N,K", [("NT", 4096, 3072, 768), ("NN", 2048, 768, 3072), ("TN", 768, 3072, 2048), ("NT", 8192, 4096, 768)])
+def test_gemm_linearity_at_real_shapes(cuda, mode, M, N, K):
+    """A (x + y) = A x + A y and (2A) x = 2 (A x) to fp32 rounding, in both planning modes, at shapes of the adapt step."""
+    from dynamic_asr_eval_amd import ops
+    ta, tb = mode[0] == "T", mode[1] == "T"
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g).to(cuda)
+    b1 = torch.randn((N, K) if tb else (K, N), generator=g).to(cuda)
+    b2 = torch.randn((N, K) if tb else (K, N), generator=g).to(cuda)
+    def mm(a_, b_):
+        c = torch.empty(M, N, device=cuda)
+        ops.gemm(a_, b_, c, trans_a=ta, trans_b=tb, M=M, N=N, K=K, lda=a_.shape[1], ldb=b_.shape[1], ldc=N)
+        return c
+    for shared in (0, 1):
+        ops.GEMM_SHARED_GPU = shared
+        try:
+            c1, c2, c12 = mm(a, b1), mm(a, b2), mm(a, b1 + b2)
+            scale = (c1.abs().max() + c2.abs().max()).item()
+            assert (c12 - (c1 + c2)).abs().max().item() < 1e-5 * scale * 4
+            assert torch.equal(mm(2 * a, b1), 2 * c1)            # scaling by a power of two is exact in fp32
+        finally:
+            ops.GEMM_SHARED_GPU = 0
