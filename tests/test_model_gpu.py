@@ -302,3 +302,28 @@ def test_batch_renorm_eval_mode_parity(cuda):
     o = lib.dynamic_eval(_args(optim_lr=1e-4, epochs=1, shuffle=False, spec_augment_fixed_masks=masks, quiet=True), hip, spec, 512, 256, tok,
                          use_tqdm=False)
     assert np.abs(o - o_ref).max() < 1e-3 and np.array_equal(o.argmax(-1), o_ref.argmax(-1))
+
+
+def test_dynamic_eval_with_empty_pseudo_labels(cuda):
+    """A window whose greedy transcript is empty (all blank) still takes its adapt step: CTC against an empty target is
+    -sum_t log p(blank) (torch.nn.CTCLoss with target_lengths = 0, what the reference's tokenizer.encode('') leads to,
+    lib.py:569-575).  Parity with the oracle on that path, and the weights do move."""
+    from oracle import dynamic_eval_ref as R
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    ref, hip = _pair(cuda, SMALL, vocab=128, seed=9, blank_bias=9.0)
+    tok = SyntheticTokenizer(128)
+    spec = torch.randn(1, 80, 1100, generator=torch.Generator().manual_seed(6))
+    _, keys = R.prepare_chunks(spec, 512, 256)
+    masks = _masks_for(keys, 80, None, seed=3)
+    out_ref, params_ref = R.dynamic_eval_ref(ref, spec, 512, 256, tok, MADGRAD_REF, {'lr': 1e-4}, {}, epochs=1, shuffle=False,
+                                             fixed_masks=masks, return_params=True)
+    assert (out_ref.argmax(-1) == 128).all(), "the fixture is meant to decode to nothing"
+    out, params = lib.dynamic_eval(_args(optim_lr=1e-4, epochs=1, shuffle=False, spec_augment_fixed_masks=masks, quiet=True), hip, spec,
+                                   512, 256, tok, use_tqdm=False, return_params=True)
+    assert np.abs(out - out_ref).max() < 1e-3 and np.array_equal(out.argmax(-1), out_ref.argmax(-1))
+    moved = max((a - b.detach()).abs().max().item() for a, b in zip(params_ref, ref.parameters()))
+    assert moved > 1e-7
+    for a, b in zip(params, params_ref):
+        assert (a - b).abs().max().item() < 5e-5
