@@ -209,7 +209,7 @@ def main():
                          "sampled_launches": (prof["exclusive"]["sampled"], prof["shared"]["sampled"]) if prof else 0,
                          "gemm_tflop_per_step": round(prof["flops"] * (WEVERY if a.graphs else 1) / a.steps / 1e12, 2) if prof else None,
                          "sampling": f"every 4th GEMM launch of every {WEVERY}th window step (those steps run eagerly; the rest replay "
-                                     "hipGraphs); `achieved` = launches timed with the other chains drained and planned for an exclusive GPU (kernel's own duration), "
+                                     "hipGraphs); `achieved` = launches timed with the other chains drained (kernel's own duration), "
                                      "`achieved_shared` = launches timed while the other chains share the GPU"
                                      if a.graphs else "every 4th GEMM launch"},
             "wer_counters": list(counts),

@@ -165,28 +165,18 @@ def gemm_profile_tick():
 
 def gemm_profile_mode(kind):
     """Set by the dynamic-eval loop right before each model call of a step (chains interleave on one host thread)."""
-    global GEMM_SHARED_GPU
     prof = GEMM_PROFILE
     if prof is not None:
         prof["eager_now"] = kind > 0
         prof["exclusive_now"] = kind == 2
-        # an exclusive sample has the GPU to itself (the device was drained): it is planned like any launch that does,
-        # with the latency table; every other step gets the job's planning mode back
-        if kind == 2:
-            prof.setdefault("saved_shared", GEMM_SHARED_GPU)
-            GEMM_SHARED_GPU = 0
-        elif "saved_shared" in prof:
-            GEMM_SHARED_GPU = prof.pop("saved_shared")
 
 
 def gemm_profile_stop():
     """-> dict(calls, flops, sampled, sampled_flops, sampled_ms): call after a stream synchronize."""
-    global GEMM_PROFILE, GEMM_SHARED_GPU
+    global GEMM_PROFILE
     prof, GEMM_PROFILE = GEMM_PROFILE, None
     if prof is None:
         return None
-    if "saved_shared" in prof:
-        GEMM_SHARED_GPU = prof.pop("saved_shared")
     out = {"calls": prof["calls"], "flops": prof["flops"], "bytes": prof["bytes"]}
     for key, name in (("samples", "shared"), ("samples_excl", "exclusive")):
         out[name] = {"sampled": len(prof[key]), "flops": sum(s[0] for s in prof[key]),
