@@ -43,7 +43,6 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_windows", type=int, default=1)
     ap.add_argument("--graphs", type=int, default=1, help="hipGraph replay of the per-window launch sequences")
-    ap.add_argument("--gemm_shared", type=int, default=-1, help="-1: GEMM plans for a shared GPU when chains > 1 (default); 0/1: pin")
     ap.add_argument("--final_batch", type=int, default=4, help="windows per forward in the final pass (they are independent)")
     ap.add_argument("--pcie", type=int, default=0, help="1: recordings start in HOST memory and results come back as numpy (the "
                     "PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
@@ -71,8 +70,6 @@ def make_args(a):
     ns.__dict__.update(dict(optim_lr=a.lr, epochs=1, shuffle=False, online=bool(a.online), quiet=True,
                             spec_augment_n_freq_masks=6, spec_augment_freq_mask_param=34, spec_augment_n_time_masks=0,
                             use_graphs=bool(a.graphs), final_pass_batch=a.final_batch))
-    if a.gemm_shared >= 0:
-        ns.gemm_shared_gpu = a.gemm_shared
     return ns
 
 
@@ -195,7 +192,6 @@ def main():
                        "recording_seconds": a.seconds, "windows_per_recording": len(lib.prepare_chunks(specs[0], a.seq_len, a.overlap)[1]),
                        "sharding": f"{world} ranks x {a.steps} recordings, no data-path collective",
                        "chains_per_gpu": n_chains, "hip_graphs": bool(a.graphs), "pcie_inclusive": bool(a.pcie),
-                       "gemm_plans": "shared-gpu table" if (a.gemm_shared == 1 or (a.gemm_shared < 0 and n_chains > 1)) else "latency table",
                        "blank_bias": round(a.blank_bias, 4), "hyp_tokens_per_recording": [len(h) for h in hyps]},
             "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -27,7 +27,7 @@ class GemmDesc(ctypes.Structure):
         ("nb1", ctypes.c_int64), ("nb2", ctypes.c_int64),
         ("split_k", ctypes.c_int32),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
-        ("tile_m", ctypes.c_int32), ("tile_n", ctypes.c_int32), ("tail_slices", ctypes.c_int32), ("shared_gpu", ctypes.c_int32),
+        ("tile_m", ctypes.c_int32), ("tile_n", ctypes.c_int32), ("tail_slices", ctypes.c_int32), ("reserved_", ctypes.c_int32),
         ("C_in", ctypes.c_void_p),
     ]
 

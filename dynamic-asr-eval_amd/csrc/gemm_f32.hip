@@ -541,10 +541,8 @@ Plan make_plan(const dyn_gemm_desc* d) {
     }
     const int64_t batch = d->nb1 * d->nb2;
     if (d->split_k == 0) {
-        const Tuned* table = d->shared_gpu ? kTunedShared : kTuned;
-        const int n = d->shared_gpu ? kNumTunedShared : kNumTuned;
-        for (int i = 0; i < n; ++i) {
-            const Tuned& t = table[i];
+        for (int i = 0; i < kNumTuned; ++i) {
+            const Tuned& t = kTuned[i];
             if (t.ta == (d->trans_a != 0) && t.tb == (d->trans_b != 0) && t.M == d->M && t.N == d->N && t.K == d->K && t.batch == batch) {
                 eval_config(d, t.bm, t.bn, t.split, t.tail, &best, &cost);
                 return best;
@@ -563,7 +561,7 @@ Plan make_plan(const dyn_gemm_desc* d) {
             const int s = split_opts[so];
             if (d->split_k == 0 && s > 1 && (d->K / s < 256)) continue;
             Plan pl;
-            eval_config(d, bm, bn, s, (d->split_k == 0 && !d->shared_gpu) ? -1 : 1, &pl, &cost);
+            eval_config(d, bm, bn, s, d->split_k == 0 ? -1 : 1, &pl, &cost);
             if (cost < best_cost) { best_cost = cost; best = pl; }
         }
     }

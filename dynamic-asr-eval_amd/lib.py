@@ -435,16 +435,11 @@ def dynamic_eval_ctc_loss(args, model, spec, seq_len, overlap, tokenizer, use_tq
     gen = _dynamic_eval_gen(args, model, spec, seq_len, overlap, tokenizer, use_tqdm=use_tqdm, optim=optim,
                             optimizer_state=optimizer_state, beam_search_fn=beam_search_fn, return_params=return_params,
                             return_device=return_device)
-    prev_mode = ops.GEMM_SHARED_GPU
-    if 'gemm_shared_gpu' in args.__dict__:
-        ops.GEMM_SHARED_GPU = int(args.gemm_shared_gpu)
     try:
         while True:
             next(gen)
     except StopIteration as stop:
         return stop.value
-    finally:
-        ops.GEMM_SHARED_GPU = prev_mode
 
 
 _CHAIN_STREAMS = {}
@@ -464,9 +459,6 @@ def dynamic_eval_many(args, models, specs, seq_len, overlap, tokenizer, **kw):
     main = torch.cuda.current_stream(device)
     for st in streams:
         st.wait_stream(main)
-    # plan GEMMs for throughput while chains share the GPU (args.gemm_shared_gpu pins the mode: the two planning modes sum in
-    # different orders, so bit-for-bit comparisons between one and several chains must run in the same mode)
-    prev_mode, ops.GEMM_SHARED_GPU = ops.GEMM_SHARED_GPU, int(args.__dict__.get('gemm_shared_gpu', len(models) > 1))
     pending = list(enumerate(specs))
     results = [None] * len(specs)
     free, active = list(range(len(models)))[::-1], []
@@ -486,7 +478,6 @@ def dynamic_eval_many(args, models, specs, seq_len, overlap, tokenizer, **kw):
                     free.append(ci)
     for st in streams:
         main.wait_stream(st)
-    ops.GEMM_SHARED_GPU = prev_mode
     return results
 
 

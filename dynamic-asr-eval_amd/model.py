@@ -224,7 +224,7 @@ class SCConformerXL:
             self._ctx_static = False
             return self._forward_eager(x)
         G = self._graphs
-        key = (tuple(x.shape), torch.is_grad_enabled(), self.fused_convmod, ops.GEMM_SHARED_GPU)   # GEMM plans are frozen at capture
+        key = (tuple(x.shape), torch.is_grad_enabled(), self.fused_convmod)
         ent = G["fwd"].get(key)
         if ent is None:
             G["seen"][key] = G["seen"].get(key, 0) + 1

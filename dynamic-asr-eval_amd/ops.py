@@ -107,7 +107,6 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha
     d.C_in = (c_in.data_ptr() + 4 * c_off) if c_in is not None else None   # residual source (same addressing as C)
     d.nb1, d.nb2 = nb1, nb2
     d.split_k = split_k
-    d.shared_gpu = GEMM_SHARED_GPU
     ws = workspace(c.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     prof = GEMM_PROFILE
@@ -127,7 +126,6 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha
 
 
 GEMM_PROFILE = None
-GEMM_SHARED_GPU = 0   # 1 while several recording chains share the GPU (lib.dynamic_eval_many): dyn_gemm_desc.shared_gpu
 
 
 def GEMM_PROFILE_EAGER():

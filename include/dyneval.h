@@ -56,11 +56,7 @@ typedef struct {
     /* optional forced configuration (0 = planner: tuned table for known shapes, cost model otherwise); used by
      * scripts/tune_gemm.py to time candidates: tile 64|128 x 64|128, tail_slices = K-slices of the last partial
      * round of workgroups (1 = off) */
-    int32_t tile_m, tile_n, tail_slices;
-    /* 0 = the launch has the GPU to itself (plan for shortest latency: tail slicing on);  1 = several independent launch
-     * streams share the GPU (recording chains): plan for least CU-time per FLOP — the table tuned under sharing, no tail
-     * slicing (its extra slab traffic and reduce launch only pay when CUs would otherwise idle) */
-    int32_t shared_gpu;
+    int32_t tile_m, tile_n, tail_slices, reserved_;
     /* optional residual source: C = alpha*A@B + beta*C_in (+ bias), C_in addressed exactly like C (same ldc / batch
      * strides); NULL = accumulate in place.  Lets `x_new = x + f(x)` keep x intact for the backward without a copy. */
     const float* C_in;

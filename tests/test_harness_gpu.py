@@ -43,7 +43,7 @@ def test_run_dynamic_eval_full(cuda, tmp_path, capsys):
     assert "overlap: 256\t seq_len: 512\t WER:" in open(tmp_path / "log.txt").read()
     # several recordings in flight (chains=2): same transcripts as one at a time when the masks do not depend on draw order
     noaug = ["-c", ckpt, "-seq", "512", "-o", "256", "-ds", "-nv", "-epochs", "1", "-kwargs", "optim_lr=1e-5", "vocab_size=128", "quiet=True",
-             "spec_augment_n_freq_masks=0", "gemm_shared_gpu=1"]
+             "spec_augment_n_freq_masks=0"]
     res = {}
     for chains in (1, 2):
         sp = str(tmp_path / f"c{chains}.pkl")
@@ -80,7 +80,7 @@ def test_run_seq_eval_outer_windows(cuda, tmp_path, capsys):
     from dynamic_asr_eval_amd import lib, run_dynamic_eval_full as H, run_seq_eval as S
     ckpt = _ckpt(tmp_path, cuda)
     common = ["-c", ckpt, "-seq", "512", "-o", "256", "-ds", "-nv", "-epochs", "1", "-kwargs", "optim_lr=1e-5", "vocab_size=128", "quiet=True",
-              "spec_augment_n_freq_masks=0", "min_minutes=0", "gemm_shared_gpu=1"]
+              "spec_augment_n_freq_masks=0", "min_minutes=0"]
     full = str(tmp_path / "full.pkl")
     H.main(lib.apply_args(H.build_parser(), ["-d", "synthetic_small", "-s", full] + common))
     whole = str(tmp_path / "whole.pkl")

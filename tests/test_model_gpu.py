@@ -242,7 +242,7 @@ def test_chains_and_graphs_are_bit_identical_to_the_sequential_eager_loop(cuda):
     masks = _masks_for(keys, 80, None, seed=9)
 
     def args(graphs):
-        return _args(optim_lr=1e-4, quiet=True, use_graphs=graphs, spec_augment_fixed_masks=masks, gemm_shared_gpu=1)   # one planning mode
+        return _args(optim_lr=1e-4, quiet=True, use_graphs=graphs, spec_augment_fixed_masks=masks)
 
     eager = [lib.dynamic_eval(args(False), hip, s, seq_len, overlap, tok, use_tqdm=False) for s in specs]
     graphed = [lib.dynamic_eval(args(True), hip, s, seq_len, overlap, tok, use_tqdm=False) for s in specs]
