@@ -43,9 +43,7 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_windows", type=int, default=1)
     ap.add_argument("--graphs", type=int, default=1, help="hipGraph replay of the per-window launch sequences")
-<<<<<<< HEAD
     ap.add_argument("--final_batch", type=int, default=4, help="windows per forward in the final pass (they are independent)")
-=======
     ap.add_argument("--pcie", type=int, default=0, help="1: recordings start in HOST memory and results come back as numpy (the "
                     "PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
     ap.add_argument("--chains", type=int, default=3, help="independent recordings in flight per GPU (own stream + model replica)")
@@ -71,10 +69,7 @@ def make_args(a):
     ns.config = {'model': {'subsampling_factor': 8}, 'audio_chunking': {'size': 16384, 'overlap': 0}, 'training': {'max_seq_len': 0}}
     ns.__dict__.update(dict(optim_lr=a.lr, epochs=1, shuffle=False, online=bool(a.online), quiet=True,
                             spec_augment_n_freq_masks=6, spec_augment_freq_mask_param=34, spec_augment_n_time_masks=0,
-<<<<<<< HEAD
                             use_graphs=bool(a.graphs), final_pass_batch=a.final_batch))
-=======
-                            use_graphs=bool(a.graphs)))
     return ns
 
 
