@@ -171,3 +171,18 @@ def test_tedlium_and_chime6_shaped_adapters_through_the_harness(cuda, tmp_path):
         if act.dest == 'dataset':
             act.choices = list(D.datasets_functions.keys())
     assert H.main(lib.apply_args(p, ["-d", "tiny_ted"] + _argv(ckpt, []))) >= 0
+
+
+def test_run_in_dataset_eval_and_run_alias(cuda, tmp_path, capsys):
+    """reference run_in_dataset_eval.py: adapt on recording 0, evaluate the rest with the adapted weights (epochs = 0);
+    reference run.py is the run_dynamic_eval_full flow."""
+    from dynamic_asr_eval_amd import lib, run as R0, run_dynamic_eval_full as H, run_in_dataset_eval as I
+    assert R0.main is H.main
+    ckpt = _ckpt(tmp_path, cuda)
+    save = str(tmp_path / "ind.pkl")
+    I.main(lib.apply_args(I.build_parser(), ["-d", "synthetic_small", "-s", save, "-ao", "0", "-log", str(tmp_path / "l.txt")] + _argv(ckpt, ["chains=2"])))
+    d = pickle.load(open(save.replace(".pkl", "_1.pkl"), "rb"))
+    assert set(d) >= {"wer", "words", "ins_rate", "del_rate", "sub_rate", "model_output", "gold", "args_dict", "repeat"}
+    assert len(d["model_output"]) == 2                       # 3 test recordings: the first is only adapted on
+    out = capsys.readouterr().out
+    assert "Using adapt_overlap=0" in out and "WER: " in out and "Average WER: " in out
