@@ -83,4 +83,7 @@ def max_over_ranks(value):
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])   # RCCL: name the device instead of letting torch guess it
+        else:
+            dist.barrier()

@@ -233,11 +233,13 @@ class SCConformerXL:
                 return self._forward_eager(x)
             if G["pool"] is None:
                 G["pool"] = torch.cuda.graph_pool_handle()
+            # capture_error_mode="thread_local": other threads of the process (the RCCL watchdog of a multi-rank run) may
+            # touch the HIP runtime while this thread captures; only this thread's calls are part of the capture
             static_in = x.clone()
             graph = torch.cuda.CUDAGraph()
             prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None      # no event records inside a capture
             try:
-                with torch.cuda.graph(graph, pool=G["pool"]):
+                with torch.cuda.graph(graph, pool=G["pool"], capture_error_mode="thread_local"):
                     out = self._forward_eager(static_in)
             finally:
                 ops.GEMM_PROFILE = prof
@@ -406,7 +408,7 @@ class SCConformerXL:
             graph = torch.cuda.CUDAGraph()
             prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
             try:
-                with torch.cuda.graph(graph, pool=G["pool"]):
+                with torch.cuda.graph(graph, pool=G["pool"], capture_error_mode="thread_local"):
                     self._backward(static_g, n_active, False)
             finally:
                 ops.GEMM_PROFILE = prof
