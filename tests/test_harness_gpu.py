@@ -186,3 +186,22 @@ def test_run_in_dataset_eval_and_run_alias(cuda, tmp_path, capsys):
     assert len(d["model_output"]) == 2                       # 3 test recordings: the first is only adapted on
     out = capsys.readouterr().out
     assert "Using adapt_overlap=0" in out and "WER: " in out and "Average WER: " in out
+
+
+def test_bench_contract(cuda):
+    """bench.py prints ONE JSON line with the driver's keys plus `roofline` (and `cpu_baseline` unless disabled)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--seconds", "200", "--steps", "2", "--warmup", "1", "--no_cpu_baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["metric"].startswith("audio-sec/s") and d["unit"] == "audio-s/s" and d["value"] > 0 and d["n_gpus"] == 1 and d["steps"] == 2
+    assert d["dtype"] == "f32" and d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["traffic"] is None or rf["traffic"] > 0
