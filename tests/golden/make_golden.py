@@ -7,6 +7,7 @@
   stitch_toy.json       — coverage counts of a 3-window toy worked by hand from reference lcasr/lib.py:615-629.
   tokenizer_128.model   — data asset copied from /root/reference/lcasr_nemo/tokenizer.model (SentencePiece, 128 pieces):
                           the only tokenizer the reference ships.
+  speaker_manifest_15x15.json — data asset copied from /root/reference/lcasr/results/gender_eval_tedlium/ (talk ids per gender).
   softdtw_17x15x2.npz   — soft-DTW value/gradient at the reference's first self-check shape (soft_dtw_cuda.py:426),
                           produced by oracle/softdtw_ref.py (the reference's numba code cannot run here).
 """
@@ -100,6 +101,9 @@ def main():
     json.dump({"seq_len": 32, "overlap": 16, "downsample": 8, "keys": [0, 16, 32], "u_lens": [32, 32, 24],
                "counts": [1, 1, 2, 2, 2, 2, 1]}, open(os.path.join(HERE, "stitch_toy.json"), "w"))
     shutil.copyfile(os.path.join(REF, "lcasr_nemo", "tokenizer.model"), os.path.join(HERE, "tokenizer_128.model"))
+    # data asset: the 15 female + 15 male TEDLIUM talks of the reference's cross-gender evaluation
+    shutil.copyfile(os.path.join(REF, "lcasr", "results", "gender_eval_tedlium", "speaker_manifest_15x15.json"),
+                    os.path.join(HERE, "speaker_manifest_15x15.json"))
     from oracle.softdtw_ref import softdtw_forward_backward, sqdist
     torch.manual_seed(1234)
     a = torch.rand(4, 17, 2).numpy(); b = torch.rand(4, 15, 2).numpy()

@@ -205,3 +205,26 @@ def test_bench_contract(cuda):
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["traffic"] is None or rf["traffic"] > 0
+
+
+def test_run_cross_speaker_gender(cuda, tmp_path, capsys):
+    """reference run_cross_speaker_gender_tedlium.py with a 2 + 2 manifest over the TEDLIUM-shaped synthetic talks."""
+    import json
+    from dynamic_asr_eval_amd import datasets as D, lib, run_cross_speaker_gender_tedlium as G
+    D.datasets_functions['tiny_ted4'] = lambda split: D.get_text_and_audio_synthetic_tedlium(
+        split, durations_s=[9.0, 7.0] if split == 'test' else [8.0, 6.0])
+    man = str(tmp_path / "m.json")
+    json.dump({'name': 't', 'female': [{'talk_id': 'synthetic_tedlium_test_000'}, {'talk_id': 'synthetic_tedlium_dev_001'}],
+               'male': [{'talk_id': 'synthetic_tedlium_test_001'}, {'talk_id': 'synthetic_tedlium_dev_000'}]}, open(man, 'w'))
+    ckpt = _ckpt(tmp_path, cuda)
+    p = G.build_parser()
+    for act in p._actions:
+        if act.dest == 'dataset':
+            act.choices = list(D.datasets_functions.keys())
+    save = str(tmp_path / "g.pkl")
+    G.main(lib.apply_args(p, ["-d", "tiny_ted4", "--speaker_manifest", man, "-s", save] + _argv(ckpt, [])))
+    d = pickle.load(open(save.replace(".pkl", "_1.pkl"), "rb"))
+    assert set(d) >= {"male_baseline", "female_baseline", "male_to_male", "male_to_female", "female_to_female", "female_to_male", "args_dict", "repeat"}
+    assert len(d["male_to_male"]) == 2 and len(d["female_to_male"]) == 2 and "wer" in d["male_to_female"][0]
+    out = capsys.readouterr().out
+    assert "Male baseline WER" in out and "Female baseline WER" in out and "2 female, 2 male" in out

@@ -286,3 +286,11 @@ def test_oracle_loop_reproduces_the_committed_trace():
     out = R.dynamic_eval_ref(ref, torch.from_numpy(d["spec"]), 512, 256, SyntheticTokenizer(128), MADGRAD, {'lr': float(d["lr"])}, {},
                              epochs=1, shuffle=False, online=False, fixed_masks=masks)
     assert np.abs(out - d["logits"]).max() < 1e-4 and np.array_equal(out.argmax(-1).astype(np.int32), d["argmax"])
+
+
+def test_speaker_manifest_loader_on_the_reference_manifest():
+    """reference run_cross_speaker_gender_tedlium.py:31-39 on the manifest the reference ships (15 + 15 talks)."""
+    from dynamic_asr_eval_amd.run_cross_speaker_gender_tedlium import DEFAULT_SPEAKER_MANIFEST, load_speaker_manifest
+    manifest, gender = load_speaker_manifest(DEFAULT_SPEAKER_MANIFEST)
+    assert len(manifest['female']) == 15 and len(manifest['male']) == 15 and len(gender) == 30
+    assert gender['JaneMcGonigal_2010.sph'] == 'F' and sorted(set(gender.values())) == ['F', 'M']
