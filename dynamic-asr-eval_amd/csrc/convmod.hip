@@ -3,14 +3,14 @@
 // model(audio_signal=...), reference lcasr/lib.py:550; `conv_kernel_size: 9`, earnings_finetune/lcasr160rb1.yaml:15).
 //   u [B, T, 2C]  ->  s [B, T, C] = SiLU(norm_C(bias + sum_j w[c, j] * GLU(u)[t + j - 4, c]) * gamma (+ beta))
 // Unfused this is four HBM-bound launches (GLU, dwconv, norm, SiLU) and three round trips of a [B, T, C] tensor.
-// One 256-thread workgroup owns TT = 16 consecutive frames of one sample and ALL channels (C = 256 * NV, a thread owns
+// One 256-thread workgroup owns TT = 4 consecutive frames of one sample and ALL channels (C = 256 * NV, a thread owns
 // channels tid, tid + 256, ...: coalesced), slides the GLU window through registers (halo frames are recomputed, never
 // re-read from a neighbour), and finishes the per-frame channel statistics with one wavefront + LDS reduction for the
 // whole tile.  With `save` the GLU output, the conv output and rstd/mean are also written for the (unfused) backward.
 #include "common.h"
 
 namespace {
-constexpr int TT = 16, KW = 9, P = 4, TPB = 256;
+constexpr int TT = 4, KW = 9, P = 4, TPB = 256;   // TT = 4: 1024 workgroups at B = 2, T = 2048 (16 gave 256 = one per CU: latency-bound, 1.4 TB/s)
 
 template <int NV, bool LAYERNORM>
 __global__ __launch_bounds__(TPB) void convmod_fwd_kernel(const float* __restrict__ u, const float* __restrict__ w,

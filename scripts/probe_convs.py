@@ -31,3 +31,10 @@ for rows, C in ((2048, 768), (2048, 3072), (2048, 4096), (8192, 768)):
     x = torch.randn(rows, C, device=dev); out = torch.zeros(C, device=dev)
     us = timeit(lambda: ops.colsum(x, out, beta=1.0), n=50)
     print(f"colsum [{rows},{C}] {us:7.1f} us  {rows*C*4/us/1e6:6.2f} TB/s", flush=True)
+for B in (2, 1):
+    C = 768
+    u = torch.randn(B, 2048, 2 * C, device=dev); wc = torch.randn(C, 9, device=dev); bc = torch.randn(C, device=dev); gm = torch.ones(C, device=dev)
+    for save in (True, False):
+        us = timeit(lambda: ops.convmod_fwd(u, wc, bc, gm, None, False, 1e-5, save), n=30)
+        mb = (u.numel() + B * 2048 * C * (4 if save else 1)) * 4 / 1e6
+        print(f"convmod_fwd B={B} save={save}: {us:7.1f} us  {mb/us*1e6/1e6:6.2f} TB/s ({mb:.0f} MB)", flush=True)
