@@ -294,3 +294,11 @@ def test_speaker_manifest_loader_on_the_reference_manifest():
     manifest, gender = load_speaker_manifest(DEFAULT_SPEAKER_MANIFEST)
     assert len(manifest['female']) == 15 and len(manifest['male']) == 15 and len(gender) == 30
     assert gender['JaneMcGonigal_2010.sph'] == 'F' and sorted(set(gender.values())) == ['F', 'M']
+
+
+def test_bench_chain_count_avoids_a_lone_last_recording():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    assert [m.pick_chains(3, k) for k in (1, 2, 3, 4, 5, 6, 10)] == [1, 2, 3, 2, 3, 3, 2]
+    assert m.pick_chains(1, 7) == 1
