@@ -302,3 +302,29 @@ def test_bench_chain_count_avoids_a_lone_last_recording():
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     assert [m.pick_chains(3, k) for k in (1, 2, 3, 4, 5, 6, 10)] == [1, 2, 3, 2, 3, 3, 2]
     assert m.pick_chains(1, 7) == 1
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is a checker: no module of the product package (or bench.py outside its cpu_baseline leg) may import it."""
+    import ast, glob
+    pkg = os.path.join(ROOT, "dynamic-asr-eval_amd")
+    for path in glob.glob(os.path.join(pkg, "*.py")):
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") for n in names), f"{path} imports the oracle"
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
+        assert not uses or fn.name == "cpu_baseline", f"bench.py:{fn.name} imports the oracle"
+    # and the product fails loudly, not silently, when the HIP library is absent
+    from dynamic_asr_eval_amd import _lib
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['DYN_LIB_PATH'] = '/nonexistent/libdyneval_hip.so'\n"
+            "from dynamic_asr_eval_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.DynError as e:\n    print('DynError', 'no CPU fallback' in str(e))\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.stdout.strip() == "DynError True", out.stdout + out.stderr
