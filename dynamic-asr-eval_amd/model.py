@@ -119,6 +119,7 @@ class SCConformerXL:
         self.layers = [_Group(self, f"layers.{l}.") for l in range(cfg["n_layers"])]
         self.decoder = _Group(self, "decoder.", num_classes=self.num_classes)
         self._rot = {}
+        self.fused_attention = True   # no-grad passes use dyn_attention_fwd when the launch fills the chip (see _attn_fwd)
         self._ws = None             # this model's scratch buffer (ops.use_workspace): never shared with another chain
         self._ctx = None
         self._skip_wgrad = False
@@ -224,7 +225,7 @@ class SCConformerXL:
             self._ctx_static = False
             return self._forward_eager(x)
         G = self._graphs
-        key = (tuple(x.shape), torch.is_grad_enabled(), self.fused_convmod)
+        key = (tuple(x.shape), torch.is_grad_enabled(), self.fused_convmod, self.fused_attention)
         ent = G["fwd"].get(key)
         if ent is None:
             G["seen"][key] = G["seen"].get(key, 0) + 1
@@ -330,6 +331,10 @@ class SCConformerXL:
         qkv = ops.linear(n, P[p + ".qkv.weight"], P[p + ".qkv.bias"])
         cos, sin = self._rotary(T)
         ops.rotary(qkv, cos, sin, B, T, 2 * H, D, 3 * HD)
+        if lc is None and self.fused_attention and D == 128 and B * H * ((T + 127) // 128) >= 320:
+            # no-grad pass with enough (batch, head, query-block) workgroups to fill the chip: fused kernel, scores stay on chip
+            O = ops.attention_fwd(qkv, B, T, H, D, 1.0 / math.sqrt(D))
+            return ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], out=h, beta=1.0)
         S = torch.empty(B, H, T, T, device=h.device, dtype=torch.float32)
         ops.gemm(qkv, qkv, S, trans_b=True, M=T, N=T, K=D, lda=3 * HD, ldb=3 * HD, ldc=T, nb1=B, nb2=H,
                  sa=(T * 3 * HD, D), sb=(T * 3 * HD, D), sc=(H * T * T, T * T), b_off=HD, alpha=1.0 / math.sqrt(D))

@@ -296,6 +296,17 @@ def specaug_timemask(x, t0, width, value=0.0):
     return x
 
 
+def attention_fwd(qkv, B, T, H, D, scale, out=None):
+    """Fused no-grad attention on the packed [B, T, 3 * H * D] QKV activation (q | k | v, head h at +h * D) -> [B, T, H * D]."""
+    _cc(qkv, "attention.qkv")
+    HD = H * D
+    out = torch.empty(B, T, HD, device=qkv.device, dtype=F32) if out is None else out
+    base = qkv.data_ptr()
+    check(_L().dyn_attention_fwd(base, base + 4 * HD, base + 8 * HD, out.data_ptr(), B, T, H, D, 3 * HD, T * 3 * HD, HD, T * HD, scale,
+                                 _stream()), "dyn_attention_fwd")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- norms
 def layernorm(x, gamma, beta, eps=1e-5, out=None):
     _cc(x, "layernorm.x"); _cc(gamma, "layernorm.gamma")

@@ -205,6 +205,16 @@ int dyn_cutout(float* x, int64_t F, int64_t T, const int32_t* rects, int64_t n_r
                float* means_scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused self-attention forward for no-grad passes (reference lcasr/lib.py:603: the final pass runs model(audio_signal) under
+ * torch.no_grad(); also every epochs = 0 evaluation): out = softmax(q k^T * scale) v per (batch, head), fp32, online softmax,
+ * K/V tiles staged in LDS — the [T, T] scores never reach HBM.  q / k / v are views of [B, T, .] activations with a common row
+ * and batch stride (the packed QKV activation: three base pointers), head h at +h * head_dim; head_dim must be 128.
+ * ------------------------------------------------------------------------------------------------ */
+int dyn_attention_fwd(const float* q, const float* k, const float* v, float* out, int64_t B, int64_t T, int64_t H,
+                      int64_t head_dim, int64_t row_stride, int64_t batch_stride, int64_t out_row_stride,
+                      int64_t out_batch_stride, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * CTC.  dyn_ctc_greedy replaces GreedyCTCDecoder on a CPU copy of the posteriors (reference lcasr/lib.py:498,
  * 559,565; run_dynamic_eval_full.py:53,100): argmax over classes (first maximum), collapse repeats, drop `blank`.
  *   log_probs [B*T rows, C] (row stride ld); argmax_ids [B*T]; out_ids [B, T] (prefix of out_len[b] valid ids).

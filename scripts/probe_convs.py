@@ -38,3 +38,18 @@ for B in (2, 1):
         us = timeit(lambda: ops.convmod_fwd(u, wc, bc, gm, None, False, 1e-5, save), n=30)
         mb = (u.numel() + B * 2048 * C * (4 if save else 1)) * 4 / 1e6
         print(f"convmod_fwd B={B} save={save}: {us:7.1f} us  {mb/us*1e6/1e6:6.2f} TB/s ({mb:.0f} MB)", flush=True)
+import math
+for B in (4, 2, 1):
+    H, D, T = 6, 128, 2048
+    qkv = torch.randn(B, T, 3 * H * D, device=dev)
+    HD = H * D
+    S = torch.empty(B, H, T, T, device=dev); O = torch.empty(B, T, HD, device=dev)
+    def unfused():
+        ops.gemm(qkv, qkv, S, trans_b=True, M=T, N=T, K=D, lda=3 * HD, ldb=3 * HD, ldc=T, nb1=B, nb2=H,
+                 sa=(T * 3 * HD, D), sb=(T * 3 * HD, D), sc=(H * T * T, T * T), b_off=HD, alpha=1.0 / math.sqrt(D))
+        ops.softmax(S, out=S)
+        ops.gemm(S, qkv, O, M=T, N=D, K=T, lda=T, ldb=3 * HD, ldc=HD, nb1=B, nb2=H, sa=(H * T * T, T * T), sb=(T * 3 * HD, D), sc=(T * HD, D), b_off=2 * HD)
+    tu = timeit(unfused, n=20)
+    tf = timeit(lambda: ops.attention_fwd(qkv, B, T, H, D, 1.0 / math.sqrt(D), out=O), n=20)
+    fl = 4.0 * B * H * T * T * D
+    print(f"attention B={B}: unfused {tu:7.1f} us ({fl/tu/1e6:5.1f} TF/s)  fused {tf:7.1f} us ({fl/tf/1e6:5.1f} TF/s)", flush=True)

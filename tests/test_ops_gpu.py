@@ -312,3 +312,20 @@ def test_specaug_mask_args_matches_device_index_kernels(cuda):
     for s_, w_ in zip(f0[:3], fw[:3]):
         ref[s_:s_ + w_] = 0.0
     assert torch.equal(c, ref)
+
+
+@pytest.mark.parametrize("B,T,H", [(1, 128, 1), (2, 100, 3), (1, 33, 2), (2, 2048, 2), (1, 257, 1)])
+def test_fused_attention_forward(cuda, B, T, H):
+    """dyn_attention_fwd (online softmax, scores never materialised) vs softmax(Q K^T / sqrt(D)) V in float64 on the packed
+    QKV activation; ragged T exercises the masked last key tile and the clamped last query block."""
+    from dynamic_asr_eval_amd import ops
+    D = 128
+    g = torch.Generator().manual_seed(B * 1000 + T + H)
+    qkv = torch.randn(B, T, 3 * H * D, generator=g) * 1.5
+    scale = 1.0 / D ** 0.5
+    out = ops.attention_fwd(qkv.to(cuda), B, T, H, D, scale)
+    x = qkv.double().view(B, T, 3, H, D)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)     # [B, H, T, D]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(B, T, H * D)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5, err
