@@ -213,8 +213,9 @@ def main():
                          "algorithmic_bytes_per_launch": round(prof["bytes"] / prof["calls"]) if prof and prof["calls"] else None,
                          "flop_per_launch": round(prof["flops"] / prof["calls"]) if prof and prof["calls"] else None,
                          "achieved_shared": None if shared is None else round(shared, 2),
-                         # whole-job check: all GEMM flops of the timed region / its wall time (every kernel, sync and gap included)
-                         "job_gemm_tflops": round(prof["flops"] * (WEVERY if a.graphs else 1) / dt / 1e12, 2) if prof else None,
+                         # whole-job check: all matrix-core flops of the timed region (GEMM launches + the fused attention of the final pass) / its wall
+                         # time (every kernel, sync and gap included)
+                         "job_gemm_tflops": round((prof["flops"] + prof["attn_flops"]) * (WEVERY if a.graphs else 1) / dt / 1e12, 2) if prof else None,
                          "gemm_launches": prof["calls"] if prof else 0,
                          "sampled_launches": (prof["exclusive"]["sampled"], prof["shared"]["sampled"]) if prof else 0,
                          "gemm_tflop_per_step": round(prof["flops"] * (WEVERY if a.graphs else 1) / a.steps / 1e12, 2) if prof else None,

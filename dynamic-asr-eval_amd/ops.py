@@ -175,7 +175,7 @@ def gemm_profile_stop():
     prof, GEMM_PROFILE = GEMM_PROFILE, None
     if prof is None:
         return None
-    out = {"calls": prof["calls"], "flops": prof["flops"], "bytes": prof["bytes"]}
+    out = {"calls": prof["calls"], "flops": prof["flops"], "bytes": prof["bytes"], "attn_flops": prof.get("attn_flops", 0.0)}
     for key, name in (("samples", "shared"), ("samples_excl", "exclusive")):
         out[name] = {"sampled": len(prof[key]), "flops": sum(s[0] for s in prof[key]),
                      "ms": sum(s[1].elapsed_time(s[2]) for s in prof[key])}
@@ -301,6 +301,8 @@ def attention_fwd(qkv, B, T, H, D, scale, out=None):
     _cc(qkv, "attention.qkv")
     HD = H * D
     out = torch.empty(B, T, HD, device=qkv.device, dtype=F32) if out is None else out
+    if GEMM_PROFILE is not None:
+        GEMM_PROFILE["attn_flops"] = GEMM_PROFILE.get("attn_flops", 0.0) + 4.0 * B * H * T * T * D   # matrix-core work outside dyn_gemm_f32
     base = qkv.data_ptr()
     check(_L().dyn_attention_fwd(base, base + 4 * HD, base + 8 * HD, out.data_ptr(), B, T, H, D, 3 * HD, T * 3 * HD, HD, T * HD, scale,
                                  _stream()), "dyn_attention_fwd")
