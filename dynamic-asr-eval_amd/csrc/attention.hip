@@ -12,7 +12,7 @@
 //   second product in this kernel's k order, so P feeds the matrix core straight from the accumulator registers — no transpose,
 //   no LDS round trip.                                                                                               64 MFMAs
 // K tile: [key][128] with the 16-B slot q of key r stored at slot q ^ (r & 15) (conflict-free ds_read_b128 across 16 keys; the
-// swizzle is applied to the SOURCE address of the direct-to-LDS load); V tile: [key][128] linear, read with ds_read_b32.
+// swizzle is applied to the SOURCE address of the direct-to-LDS load); V tile: [key][128] linear, one ds_read_b128 per key.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -121,19 +121,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int t = 0; t < 4; ++t) o[t][e] *= a;
         }
-        // O += P V: A = P straight from the accumulator registers (e = 4c + q'), B = V[key 8c + 4h + q'][32t + i]
+        // O += P V: A = P straight from the accumulator registers (e = 4c + q'), B = V[key 8c + 4h + q'][4i + t]: output tile t
+        // holds the head-dim columns 4i + t, so ONE ds_read_b128 per key feeds all four tiles (and the final store is 16 B per lane)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-                const float* vr = vs + (8 * c + 4 * h + qq) * D + i;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[4 * c + qq], vr[32 * t], o[t], 0, 0, 0);
+                const float4 vv = *reinterpret_cast<const float4*>(vs + (8 * c + 4 * h + qq) * D + 4 * i);
+                o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[4 * c + qq], vv.x, o[0], 0, 0, 0);
+                o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[4 * c + qq], vv.y, o[1], 0, 0, 0);
+                o[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[4 * c + qq], vv.z, o[2], 0, 0, 0);
+                o[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[4 * c + qq], vv.w, o[3], 0, 0, 0);
             }
         __syncthreads();   // next tile has landed (vmcnt(0)) and every wave is done reading this stage
         cur ^= 1;
     }
-    // normalise and store: O[query (e, h)][32 t + i]
+    // normalise and store: O[query (e, h)][4 i + t]
     const float inv = 1.f / l_run;
     float* ob = out + b * out_batch_stride + head * D;
 #pragma unroll
@@ -141,10 +144,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int r = (e & 3) + 8 * (e >> 2) + 4 * h;
         const float w = __shfl(inv, r, 64);
         const int64_t row = q0 + r;
-        if (row < T) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) ob[row * out_row_stride + 32 * t + i] = o[t][e] * w;
-        }
+        if (row < T)
+            *reinterpret_cast<float4*>(ob + row * out_row_stride + 4 * i) = make_float4(o[0][e] * w, o[1][e] * w, o[2][e] * w, o[3][e] * w);
     }
 }
 }  // namespace
@@ -156,8 +157,9 @@ extern "C" int dyn_attention_fwd(const float* q, const float* k, const float* v,
                                  int64_t out_batch_stride, float scale, void* stream) {
     DYN_REQUIRE(q && k && v && out && B >= 0 && T >= 0 && H > 0, DYN_E_ARG, "dyn_attention_fwd: bad arguments");
     DYN_REQUIRE(head_dim == D, DYN_E_UNSUPPORTED, "dyn_attention_fwd: head_dim %lld (the fused kernel is built for 128)", (long long)head_dim);
-    DYN_REQUIRE(row_stride % 4 == 0 && batch_stride % 4 == 0 && ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0, DYN_E_ARG,
-                "dyn_attention_fwd: q / k / v must be 16-byte aligned with strides that are multiples of 4 floats");
+    DYN_REQUIRE(row_stride % 4 == 0 && batch_stride % 4 == 0 && out_row_stride % 4 == 0 && out_batch_stride % 4 == 0 &&
+                    ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0, DYN_E_ARG,
+                "dyn_attention_fwd: q / k / v / out must be 16-byte aligned with strides that are multiples of 4 floats");
     if (B == 0 || T == 0) return DYN_OK;
     dim3 grid((unsigned)dyn::cdiv(T, BQ), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, row_stride, batch_stride,
