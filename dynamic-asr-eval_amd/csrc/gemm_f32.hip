@@ -6,17 +6,21 @@
 //
 // Design (MI355X-first, not a warp-tiled port):
 //   * 256-thread workgroup = 4 wave64 as 2(M) x 2(N); each wave owns (BM/2)x(BN/2) as 32x32 MFMA tiles,
-//     accumulators stay in registers for the whole K loop (64 VGPRs at 128x128).
-//   * BK = 32.  An operand whose K is contiguous in HBM is staged as [row][BK+4]: one ds_read_b128 per lane
-//     feeds FOUR k-steps (lane half h covers k = 8c+4h+s), and the 36-float row stride keeps every
-//     16-lane ds_read_b128 group on 16 distinct 16-B slots (conflict-free, MI355X_MICROARCH.md §LDS).
-//     An operand whose ROW index is contiguous in HBM (transposed use) is staged as [k][rows+4] and read with
-//     conflict-free ds_read_b32 (32 consecutive floats per lane half) using the same k(c,h,s) order.
-//   * global -> registers -> LDS double buffer: tile t+1's 16-B global loads are issued before tile t's MFMAs
-//     and written to the other LDS buffer after them; one barrier per K tile.
+//     accumulators stay in registers for the whole K loop (64 AGPRs at 128x128).  BK = 32.
+//   * Staging, main path: direct-to-LDS loads (global_load_lds_dwordx4, GldsStager) — no staging VGPRs, no ds_write pass.
+//     One wave-instruction writes 1 KiB of LDS linearly, so the image is unpadded and the conflict-free layout comes from
+//     the SOURCE address each lane fetches (K-contiguous operand: 16-B slot q of row r stored at q ^ ((r >> 1) & 7);
+//     row-contiguous operand: [k][rows], read with ds_read_b32).  Whole K tiles and 16-B aligned operands only; matrix
+//     edges are clamped loads.
+//   * Staging, fallback (partial K tiles, unaligned operands, lda < K implicit GEMMs): global -> registers -> LDS with
+//     the padded [row][BK+4] image (one ds_read_b128 per lane feeds FOUR k-steps: lane half h covers k = 8c+4h+s).
+//     Both paths feed the MFMAs the same operands in the same order: bit-identical results.
+//     DYN_GEMM_GLDS=0 in the environment forces the fallback everywhere (A/B measurements).
+//   * Two-level software pipeline: fragments double-buffered in registers, a tile's last chunk issued after the barrier
+//     and after the next tile's first fragment reads; one barrier per K tile.
 //   * XCD-aware bijective block remap: the 8 XCDs (private L2s) each walk a contiguous run of output tiles.
-//   * split-K writes fp32 slabs to a caller workspace and a second kernel sums them in slice order:
-//     deterministic wgrad without float atomics.
+//   * split-K writes fp32 slabs to a caller workspace and a second kernel sums them in slice order; the last partial
+//     round of workgroups is K-sliced the same way (tail slicing): deterministic, no float atomics.
 #include "common.h"
 #include <cstdlib>
 
