@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_windows", type=int, default=1)
     ap.add_argument("--graphs", type=int, default=1, help="hipGraph replay of the per-window launch sequences")
+    ap.add_argument("--sample_every", type=int, default=32, help="every n-th window step runs eagerly for the live roofline sampling "
+                    "(costs 0.7 %% of the throughput at 32: 771 vs 776 audio-s/s at 96, 775 with sampling off)")
     ap.add_argument("--final_batch", type=int, default=4, help="windows per forward in the final pass (they are independent)")
     ap.add_argument("--pcie", type=int, default=0, help="1: recordings start in HOST memory and results come back as numpy (the "
                     "PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
@@ -173,7 +175,7 @@ def main():
     # runs eagerly with a HIP-event pair around every 4th GEMM launch.  Sampled steps alternate between "shared" (the other
     # chains keep the GPU busy: the duration a launch sees in this job, what rocprofv3 of this command averages) and
     # "exclusive" (the device is drained around the step: the kernel's own duration, what rocprofv3 --chains 1 averages).
-    WEVERY = 32
+    WEVERY = max(2, a.sample_every)
     ops.gemm_profile_start(every=4, window_every=WEVERY if a.graphs else 0)
     t0 = time.perf_counter()
     hyps = run_many(specs[a.warmup:a.warmup + a.steps])
