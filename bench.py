@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_windows", type=int, default=1)
     ap.add_argument("--graphs", type=int, default=1, help="hipGraph replay of the per-window launch sequences")
+    ap.add_argument("--prewarm_s", type=float, default=40.0, help="seconds of the untimed workload BEFORE the W warm-up steps: the first "
+                    "process on an idle MI355X reads 3-10 %% low until the GPU has been under this load for some tens of seconds "
+                    "(743 -> 772 audio-s/s with 40 s; 12 s of plain GEMMs do not do it); steady state is what is reported")
     ap.add_argument("--sample_every", type=int, default=32, help="every n-th window step runs eagerly for the live roofline sampling "
                     "(costs 0.7 %% of the throughput at 32: 771 vs 776 audio-s/s at 96, 775 with sampling off)")
     ap.add_argument("--final_batch", type=int, default=4, help="windows per forward in the final pass (they are independent)")
@@ -167,6 +170,10 @@ def main():
         model.P["decoder.ff.bias"][-1] += a.blank_bias
     for m in models[1:]:                       # every chain starts from the same weights
         m.flat_params.copy_(model.flat_params)
+    if a.prewarm_s > 0:     # untimed, before the W warm-up steps: the workload itself, until the GPU has been under load for prewarm_s
+        t_end = time.perf_counter() + a.prewarm_s
+        while time.perf_counter() < t_end:
+            run_many(specs[:1] * n_chains)
     if a.warmup:
         run_many(specs[:a.warmup] * n_chains)                                  # every chain (stream, workspace) is warmed
     ddist.barrier()
@@ -207,7 +214,7 @@ def main():
                                    "6 freq masks <=34), SCConformerXL 6x768 V+1=4096 seeded weights",
                        "recording_seconds": a.seconds, "windows_per_recording": len(lib.prepare_chunks(specs[0], a.seq_len, a.overlap)[1]),
                        "sharding": f"{world} ranks x {a.steps} recordings, no data-path collective",
-                       "chains_per_gpu": n_chains, "hip_graphs": bool(a.graphs), "pcie_inclusive": bool(a.pcie),
+                       "chains_per_gpu": n_chains, "hip_graphs": bool(a.graphs), "pcie_inclusive": bool(a.pcie), "prewarm_s": a.prewarm_s,
                        "blank_bias": round(a.blank_bias, 4), "hyp_tokens_per_recording": [len(h) for h in hyps]},
             "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),

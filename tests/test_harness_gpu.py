@@ -192,7 +192,7 @@ def test_bench_contract(cuda):
     """bench.py prints ONE JSON line with the driver's keys plus `roofline` (and `cpu_baseline` unless disabled)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--seconds", "200", "--steps", "2", "--warmup", "1", "--no_cpu_baseline"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--seconds", "200", "--steps", "2", "--warmup", "1", "--no_cpu_baseline", "--prewarm_s", "0"],
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
