@@ -51,6 +51,9 @@ struct KParams {
     float* ws;        // split-K slabs [splits][batch][M][N]
     int64_t nbatch;
     int tiles_n;
+    int tiles_m;
+    int n_major;      // 1: consecutive items walk down a COLUMN of tiles (each XCD's contiguous run then shares B panels and
+                      // partitions A instead of the other way round): chosen when B is the larger operand
     int64_t tiles_per_batch;
     int64_t full_items;  // work items (batch, tile, k-split) handled by one workgroup each; the rest is the TAIL
     int tail_f;          // every tail item is cut into tail_f K-slices so the last partial round of workgroups still
@@ -243,7 +246,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
     const int64_t t2 = item / p.splits;
     const int tile = (int)(t2 % p.tiles_per_batch);
     const int zb = (int)(t2 / p.tiles_per_batch);
-    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int tm = p.n_major ? tile % p.tiles_m : tile / p.tiles_n;
+    const int tn = p.n_major ? tile / p.tiles_m : tile % p.tiles_n;
     const int64_t z1 = zb / p.nb2, z2 = zb % p.nb2;
     const float* A = p.A + z1 * p.sa1 + z2 * p.sa2;
     const float* B = p.B + z1 * p.sb1 + z2 * p.sb2;
@@ -462,7 +466,8 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(const KParams p, int B
         const int64_t item = p.full_items + ti;  // splits == 1 in tail mode
         const int tile = (int)(item % p.tiles_per_batch);
         const int zb = (int)(item / p.tiles_per_batch);
-        const int64_t row = (int64_t)(tile / p.tiles_n) * BM + r, col0 = (int64_t)(tile % p.tiles_n) * BN + c;
+        const int64_t row = (int64_t)(p.n_major ? tile % p.tiles_m : tile / p.tiles_n) * BM + r;
+        const int64_t col0 = (int64_t)(p.n_major ? tile / p.tiles_m : tile % p.tiles_n) * BN + c;
         if (row >= p.M) continue;
         const int64_t z1 = zb / p.nb2, z2 = zb % p.nb2;
         float* C = p.C + z1 * p.sc1 + z2 * p.sc2 + row * p.ldc;
@@ -633,6 +638,11 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
     kp.ws = (float*)d->workspace; kp.nbatch = batch;
     const int64_t tiles_m = dyn::cdiv(d->M, pl.bm), tiles_n = dyn::cdiv(d->N, pl.bn);
     kp.tiles_n = (int)tiles_n;
+    kp.tiles_m = (int)tiles_m;
+    // Each XCD (private L2) walks a contiguous run of items: row-major runs re-fetch all of B per XCD and A once overall,
+    // column-major runs the opposite.  Re-fetch the SMALLER operand.
+    static const bool xcd_map = [] { const char* e = getenv("DYN_GEMM_XCDMAP"); return !e || atoi(e) != 0; }();
+    kp.n_major = (xcd_map && d->N > d->M) ? 1 : 0;
     kp.tiles_per_batch = tiles_m * tiles_n;
     kp.full_items = pl.full_items;
     kp.tail_f = pl.tail_f;

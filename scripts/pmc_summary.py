@@ -23,7 +23,7 @@ n2, w = wr["gemm_f32_kernel"]
 res = {"kernel": "gemm_f32_kernel", "launches": n, "fetch_size_kib_per_launch": f / n, "write_size_kib_per_launch": w / n2,
        "hbm_bytes_per_launch": (2 * f / n + w / n2) * 1024,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0 "
-                 "--seconds 300 --no_cpu_baseline --graphs 0 --chains 1` (one chain, eager launches: per-launch traffic does not "
+                 "--seconds 300 --prewarm_s 0 --no_cpu_baseline --graphs 0 --chains 1` (one chain, eager launches: per-launch traffic does not "
                  "depend on how launches are queued); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count correction)"}
 json.dump(res, open(out, "w"), indent=1)
 print(res)
