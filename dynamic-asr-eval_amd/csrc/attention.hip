@@ -58,11 +58,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             vsrc[j] = vb + key * row_stride + 4 * pslot;
         }
     };
+    // The loads are issued from inline assembly: with the builtin, hipcc (ROCm 7.2) waits vmcnt(0) at the first LDS read after an
+    // LDS-DMA it cannot prove disjoint — here the top of every iteration, which exposed the whole load latency.  The tile in flight
+    // is waited for explicitly before the barrier that ends the iteration (M0 = LDS destination, saved and restored around the load).
+    auto glds16 = [&](const float* src, float* dst) {
+        unsigned keep;
+        const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)dst);   // wave-uniform: an SGPR
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+    };
     auto issue = [&](float* stage) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)ksrc[j], (lds_void_t*)(stage + (wave * 4 + j) * 256), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)vsrc[j], (lds_void_t*)(stage + TILE + (wave * 4 + j) * 256), 16, 0, 0);
+            glds16(ksrc[j], stage + (wave * 4 + j) * 256);
+            glds16(vsrc[j], stage + TILE + (wave * 4 + j) * 256);
         }
     };
 
@@ -76,6 +85,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int64_t ntiles = (T + BKEY - 1) / BKEY;
     set_src(0);
     issue(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (int64_t kt = 0; kt < ntiles; ++kt) {
@@ -133,7 +143,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 o[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[4 * c + qq], vv.z, o[2], 0, 0, 0);
                 o[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[4 * c + qq], vv.w, o[3], 0, 0, 0);
             }
-        __syncthreads();   // next tile has landed (vmcnt(0)) and every wave is done reading this stage
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next tile has landed ...
+        __syncthreads();                                      // ... everybody's has, and every wave is done reading this stage
         cur ^= 1;
     }
     // normalise and store: O[query (e, h)][4 i + t]
