@@ -299,7 +299,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
         store_tile<AK, BM>(smem, ra);
         store_tile<BKM, BN>(smem + SA, rb);
     }
-    __syncthreads();   // with a direct-to-LDS load in flight this also waits vmcnt(0): the tile has landed
+    // An LDS-DMA is ordered for a ds_read only by the issuing wave's vmcnt wait followed by a barrier: state the wait explicitly
+    // instead of relying on the fence hipcc attaches to __syncthreads().
+    if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     // Main loop, software-pipelined at two levels so a wave's MFMA stream never waits on LDS latency:
     //   * fragments are double-buffered in registers: chunk c+1 is read from LDS while chunk c's MFMAs issue;
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
             store_tile<AK, BM>(da, ra);
             store_tile<BKM, BN>(da + SA, rb);
         }
+        if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of tile kt+1 has landed (see the prologue)
         __syncthreads();
         if (more) read_chunk(da, da + SA, 0, 0);
         mfma_chunk((NC - 1) & 1);
