@@ -84,6 +84,25 @@ def apply_masks(window, masks, zero_masking):
     return window
 
 
+def stitch_ref(model_outputs, all_logits, logit_count):
+    """The stitch of reference lcasr/lib.py:615-629 (the same statements close run_seq_eval.py:130-144 and
+    run_within_recording_loo_eval.py): windows in key order, `logit_position -= overlap_ds` except for key 0, overlap-add
+    of the probabilities and of a coverage count, rows never covered dropped, log(sum / count).
+    model_outputs: {key: {'logits': probs [1, ds_len, C] or [ds_len, C], 'ds_len', 'overlap_ds'}}; the two accumulators are
+    zero tensors [1, rows, C].  Pinned by tests/golden/reference_pins.npz (the reference's statements executed unchanged)."""
+    logit_position = 0
+    for i in sorted(list(model_outputs.keys())):
+        logits, ds_len, overlap_ds = model_outputs[i]['logits'], model_outputs[i]['ds_len'], model_outputs[i]['overlap_ds']
+        logit_position -= overlap_ds if i != 0 else 0
+        logit_count[:, logit_position:logit_position + ds_len, :] += 1
+        all_logits[:, logit_position:logit_position + ds_len, :] += logits
+        logit_position += ds_len
+    B, N, C = all_logits.shape
+    all_logits = all_logits[logit_count.sum(dim=-1) != 0].reshape(B, -1, C)
+    logit_count = logit_count[logit_count.sum(dim=-1) != 0].reshape(B, -1, C)
+    return torch.log(all_logits / logit_count)
+
+
 def dynamic_eval_ref(model, spec, seq_len, overlap, tokenizer, optimizer_cls, lr_args, spec_augment_config, epochs=1,
                      shuffle=False, online=False, downsampling_factor=8, fixed_masks=None, return_params=False,
                      max_windows=None):
@@ -150,17 +169,7 @@ def dynamic_eval_ref(model, spec, seq_len, overlap, tokenizer, optimizer_cls, lr
             logits = torch.exp(out['final_posteriors'][0].detach())
             ds_len = logits.shape[-2]
             model_outputs[i] = {'logits': logits, 'ds_len': ds_len, 'overlap_ds': int(overlap / (u_len / ds_len))}
-    logit_position = 0
-    for i in sorted(list(model_outputs.keys())):
-        logits, ds_len, overlap_ds = model_outputs[i]['logits'], model_outputs[i]['ds_len'], model_outputs[i]['overlap_ds']
-        logit_position -= overlap_ds if i != 0 else 0
-        logit_count[:, logit_position:logit_position + ds_len, :] += 1
-        all_logits[:, logit_position:logit_position + ds_len, :] += logits
-        logit_position += ds_len
-    B, N, C = all_logits.shape
-    all_logits = all_logits[logit_count.sum(dim=-1) != 0].reshape(B, -1, C)
-    logit_count = logit_count[logit_count.sum(dim=-1) != 0].reshape(B, -1, C)
-    logits = torch.log(all_logits / logit_count)
+    logits = stitch_ref(model_outputs, all_logits, logit_count)
     if return_params:
         updated = [p.clone().detach().cpu() for p in model.parameters()]
     for p, p_orig in zip(model.parameters(), original_model_params):

@@ -1,0 +1,155 @@
+"""Holds the oracle (CPU tests) and the HIP kernels (-m gpu tests) to tests/golden/reference_pins.{npz,json}: outputs that
+the REFERENCE'S OWN functions / statements produced when executed unchanged via ast extraction in the build container
+(tests/golden/make_reference_pins.py).  Covered: frame_shuffle / add_random_noise / cutout (lcasr/lib.py:81-84,379-417),
+the four arg->config helpers (:102-125,419-428), the stitch statements (lcasr/lib.py:615-629 and run_seq_eval.py:130-144),
+the TEDLIUM STM text handling (tedlium/run.py:25-51) and SoftDTW._euclidean_dist_func (wav2vec2/soft_dtw_cuda.py:319-329)."""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def pins():
+    return np.load(os.path.join(GOLD, "reference_pins.npz")), json.load(open(os.path.join(GOLD, "reference_pins.json")))
+
+
+AUG_SHUFFLE = (("t", dict(time_dimension=True)), ("f", dict(freq_dimension=True)), ("tf", dict(time_dimension=True, freq_dimension=True)))
+
+
+def _stitch_inputs(arr, case, tag, ci):
+    flat = torch.from_numpy(arr[f"stitch_{tag}_{ci}_in"])
+    mo, row = {}, 0
+    for k, ds in zip(case["keys"], case["ds_len"]):
+        mo[k] = {"logits": flat[row:row + ds][None], "ds_len": ds, "overlap_ds": case["overlap_ds"]}
+        row += ds
+    return mo
+
+
+# ------------------------------------------------------------------------------------------------ CPU: oracle / host logic
+def test_oracle_augmentations_reproduce_the_reference_outputs(pins):
+    from oracle import augment_ref as R
+    arr, meta = pins
+    spec = torch.from_numpy(arr["aug_spec"])
+    for tag, kw in AUG_SHUFFLE:
+        torch.manual_seed(meta["aug_seeds"]["frame_shuffle"])
+        assert np.array_equal(R.frame_shuffle(spec.clone(), **kw).numpy(), arr[f"frame_shuffle_{tag}"]), tag
+    torch.manual_seed(meta["aug_seeds"]["noise"])
+    assert np.array_equal(R.add_random_noise(spec.clone(), 0.3).numpy(), arr["noise_0p3"])
+    for val in ("mean", "mean_recording", "zero"):
+        torch.manual_seed(meta["aug_seeds"]["cutout"])
+        got = R.cutout(spec.clone(), 600, cutout_val=val, num_rectangles=7, max_width=100, max_height=10).numpy()
+        assert np.array_equal(got, arr[f"cutout_{val}"]), val
+    torch.manual_seed(meta["aug_seeds"]["cutout_short"])
+    got = R.cutout(spec[:, :, :250].clone(), 600, cutout_val="mean", num_rectangles=7, max_width=40, max_height=6).numpy()
+    assert np.array_equal(got, arr["cutout_short"])
+
+
+def test_arg_helpers_reproduce_the_reference_dicts(pins):
+    from dynamic_asr_eval_amd import lib
+    _, meta = pins
+    for case in meta["arg_cases"]:
+        a = argparse.Namespace(**case["args"])
+        assert lib.get_specaugment_config_from_args(a) == case["specaugment"]
+        assert lib.get_frame_shuffle_config_from_args(a) == case["frame_shuffle"]
+        assert lib.get_lr_args_from_args(a) == case["lr"]
+        assert lib.get_cutout_params_from_args(a, 16384) == case["cutout"]
+
+
+@pytest.mark.parametrize("tag", ["inner", "outer"])
+def test_oracle_stitch_reproduces_the_reference_statements(pins, tag):
+    from oracle.dynamic_eval_ref import stitch_ref
+    arr, meta = pins
+    for ci, case in enumerate(meta[f"stitch_{tag}"]):
+        mo = _stitch_inputs(arr, case, tag, ci)
+        C, rows = case["classes"], case["acc_rows"]
+        out = stitch_ref(mo, torch.zeros(1, rows, C), torch.zeros(1, rows, C))[0].numpy()
+        want = arr[f"stitch_{tag}_{ci}_out"]
+        assert out.shape == want.shape == (case["out_rows"], C) and np.array_equal(out, want), (tag, ci)
+
+
+def test_stm_text_handling_reproduces_the_reference(pins):
+    from dynamic_asr_eval_amd.datasets import proc_stm_lines
+    _, meta = pins
+    text, timings, remove = proc_stm_lines(meta["stm"]["lines"])
+    assert text == meta["stm"]["text"] and timings == meta["stm"]["timings"] and remove == meta["stm"]["remove_timings"]
+
+
+def test_oracle_sqdist_reproduces_the_reference(pins):
+    from oracle.softdtw_ref import sqdist
+    arr, _ = pins
+    for tag in "abc":
+        want = arr[f"sqdist_{tag}_d"]
+        got = sqdist(arr[f"sqdist_{tag}_x"], arr[f"sqdist_{tag}_y"])
+        assert got.shape == want.shape and np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), tag
+
+
+# ------------------------------------------------------------------------------------------------ GPU: the HIP path
+@pytest.mark.gpu
+def test_device_augmentations_reproduce_the_reference_outputs(cuda, pins):
+    """augment.frame_shuffle / add_random_noise / cutout draw from the caller's torch CPU RNG in the reference's order and move
+    the data on the device: same seeds -> the reference's own outputs (shuffles bit-exact; means/noise to fp32 rounding)."""
+    from dynamic_asr_eval_amd import augment
+    arr, meta = pins
+    spec = torch.from_numpy(arr["aug_spec"])
+
+    def dev():
+        return spec[0].to(cuda).clone()
+
+    for tag, kw in AUG_SHUFFLE:
+        torch.manual_seed(meta["aug_seeds"]["frame_shuffle"])
+        assert np.array_equal(augment.frame_shuffle(dev(), **kw).cpu().numpy(), arr[f"frame_shuffle_{tag}"][0]), tag
+    torch.manual_seed(meta["aug_seeds"]["noise"])
+    got = augment.add_random_noise(dev(), 0.3).cpu().numpy()
+    assert np.abs(got - arr["noise_0p3"][0]).max() < 2e-5
+    for val in ("mean", "mean_recording", "zero"):
+        torch.manual_seed(meta["aug_seeds"]["cutout"])
+        got = augment.cutout(dev(), 600, cutout_val=val, num_rectangles=7, max_width=100, max_height=10).cpu().numpy()
+        assert np.abs(got - arr[f"cutout_{val}"][0]).max() < 2e-6, val
+    torch.manual_seed(meta["aug_seeds"]["cutout_short"])
+    got = augment.cutout(spec[0, :, :250].contiguous().to(cuda), 600, cutout_val="mean", num_rectangles=7, max_width=40, max_height=6).cpu().numpy()
+    assert np.abs(got - arr["cutout_short"][0]).max() < 2e-6
+
+
+@pytest.mark.gpu
+def test_device_stitch_reproduces_the_reference_statements(cuda, pins):
+    """dyn_stitch_accumulate / dyn_stitch_finalize (the loop's accumulators in HBM) and run_seq_eval.outer_stitch against the
+    outputs of the reference's stitch statements, short tail windows and a tail that lands inside earlier coverage included."""
+    from dynamic_asr_eval_amd import ops
+    from dynamic_asr_eval_amd.run_seq_eval import outer_stitch
+    arr, meta = pins
+    for ci, case in enumerate(meta["stitch_inner"]):
+        mo = _stitch_inputs(arr, case, "inner", ci)
+        C, rows = case["classes"], case["acc_rows"]
+        acc = torch.zeros(rows, C, device=cuda); cnt = torch.zeros(rows, device=cuda)
+        pos = end = 0
+        for k in sorted(mo):                                    # the position rule of lib._dynamic_eval_gen.stitch_window
+            pos -= mo[k]["overlap_ds"] if k != 0 else 0
+            ops.stitch_accumulate(torch.log(mo[k]["logits"][0]).to(cuda).contiguous(), acc, cnt, pos)
+            pos += mo[k]["ds_len"]
+            end = max(end, pos)
+        got = ops.stitch_finalize(acc, cnt, end).cpu().numpy()
+        want = arr[f"stitch_inner_{ci}_out"]
+        assert got.shape == want.shape and np.abs(got - want).max() < 5e-6, ci
+    for ci, case in enumerate(meta["stitch_outer"]):
+        mo = _stitch_inputs(arr, case, "outer", ci)
+        # outer_stitch derives overlap_ds = int(overlap / (u_len / ds_len)): u_len = 8 * ds_len, overlap = 8 * overlap_ds
+        wins = [(k, torch.log(mo[k]["logits"][0]).to(cuda).contiguous(), 8 * mo[k]["ds_len"]) for k in mo]
+        got = outer_stitch(wins, 8 * case["overlap_ds"], case["classes"], cuda).cpu().numpy()
+        want = arr[f"stitch_outer_{ci}_out"]
+        assert got.shape == want.shape and np.abs(got - want).max() < 5e-6, ci
+
+
+@pytest.mark.gpu
+def test_device_sqdist_reproduces_the_reference(cuda, pins):
+    from dynamic_asr_eval_amd.soft_dtw import sqdist
+    arr, _ = pins
+    for tag in "abc":
+        want = arr[f"sqdist_{tag}_d"]
+        got = sqdist(torch.from_numpy(arr[f"sqdist_{tag}_x"]).to(cuda), torch.from_numpy(arr[f"sqdist_{tag}_y"]).to(cuda)).cpu().numpy()
+        assert got.shape == want.shape and np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), tag
