@@ -13,7 +13,10 @@ timed region starts.  Weak scaling: every rank adapts on its own recordings (the
 fresh optimiser per call); the only collective is the WER-counter all-reduce after the timed region.
 
 Prints ONE JSON line on rank 0 with `roofline` (fp32-MFMA GEMM family, measured live with HIP events on the launch
-stream) and, at N=1, `cpu_baseline` (the CPU oracle restatement timed on the host cores on a bounded sample)."""
+stream) and, at N=1, `cpu_baseline` (the CPU oracle restatement timed on the host cores on a bounded sample), `parity`
+(the cpu_baseline windows through the HIP path with the same weights and masks, compared with the oracle's outputs),
+`value_degenerate_labels` (the model's own collapsing pseudo-labels instead of --label_tokens seeded ids per window) and
+`value_boundary` (recordings start in host memory, log-probs come back as numpy: the reference's call contract)."""
 import argparse
 import json
 import os
@@ -41,7 +44,13 @@ def parse():
     ap.add_argument("--online", type=int, default=0)
     ap.add_argument("--blank_bias", type=float, default=-1.0, help="<0: calibrate for a speech-like token rate")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_windows", type=int, default=1)
+    ap.add_argument("--cpu_windows", type=int, default=3, help="timed CPU-oracle windows (after one untimed warm-up window)")
+    ap.add_argument("--label_tokens", type=int, default=400, help="pseudo-label ids per window in the timed region: a seeded model self-training "
+                    "on noise collapses to the empty transcript within a few windows (degenerate CTC lattice, L = 1), so tokenizer.encode "
+                    "returns a fixed seeded sequence of this many ids per window (speech-like: ~2.4 tokens/s) and the lattice runs at "
+                    "L = 2 * N + 1; 0 = the model's own (collapsing) pseudo-labels, reported separately as value_degenerate_labels")
+    ap.add_argument("--side_steps", type=int, default=-1, help="recordings per side measurement (value_degenerate_labels, value_boundary); "
+                    "-1 = one round of the chains, 0 = skip them")
     ap.add_argument("--graphs", type=int, default=1, help="hipGraph replay of the per-window launch sequences")
     ap.add_argument("--prewarm_s", type=float, default=40.0, help="seconds of the untimed workload BEFORE the W warm-up steps: the first "
                     "process on an idle MI355X reads 3-10 %% low until the GPU has been under this load for some tens of seconds "
@@ -92,15 +101,41 @@ def make_args(a):
     return ns
 
 
-def cpu_baseline(a):
-    """CPU oracle (oracle/dynamic_eval_ref.py + oracle/conformer_ref.py) on a bounded sample: `cpu_windows` full
-    16384-frame windows, each = adapt step (B=2 fwd + CTC + bwd + MADGRAD) + final-pass forward + stitch; the 1 h
-    recording is 169 such windows, so audio-s/s = 3600 / (169 * seconds_per_window)."""
+class SubstituteLabelTokenizer:
+    """SyntheticTokenizer whose encode() returns a FIXED seeded id sequence of `n` tokens (bench only): the decode -> text -> encode
+    hop, the pinned upload and the CTC lattice then carry the sizes a real checkpoint produces (reference lcasr/lib.py:565-575)."""
+
+    def __init__(self, base, n, seed=4321):
+        self.base, self.n = base, int(n)
+        g = torch.Generator().manual_seed(seed)
+        self.ids = torch.randint(0, base.vocab_size(), (self.n,), generator=g).tolist()
+        self.text = base.decode(self.ids)
+
+    def vocab_size(self):
+        return self.base.vocab_size()
+
+    def decode(self, ids):
+        return self.base.decode(ids)
+
+    def encode(self, text):
+        self.base.encode(text)                      # the model's own pseudo-label text still makes the round trip
+        return self.base.encode(self.text)
+
+
+def cpu_baseline_and_parity(a, hip_model, dev):
+    """CPU oracle (oracle/dynamic_eval_ref.py + oracle/conformer_ref.py) on a bounded sample: one untimed warm-up window, then
+    `cpu_windows` full 16384-frame windows, each = adapt step (B=2 fwd + CTC + bwd + MADGRAD) + final-pass forward + stitch; the
+    1 h recording is 169 such windows, so audio-s/s = 3600 / (169 * seconds_per_window).
+    The SAME windows then go through the HIP path (lib.dynamic_eval, same weights, same stored SpecAugment masks, the model's own
+    pseudo-labels): `parity` = the largest |log-prob difference| of the adapted, stitched outputs and whether the argmax ids agree."""
+    import numpy as np
     from oracle.conformer_ref import SCConformerXLRef
-    from oracle.dynamic_eval_ref import dynamic_eval_ref
+    from oracle.dynamic_eval_ref import draw_masks, dynamic_eval_ref, greedy_ctc_ids
     from oracle.madgrad_ref import MADGRAD
+    from dynamic_asr_eval_amd import lib
     from dynamic_asr_eval_amd.datasets import synthetic_spec
     from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    from dynamic_asr_eval_amd.wer import edit_counts
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
@@ -108,19 +143,51 @@ def cpu_baseline(a):
         pass
     cores = min(cores, int(os.environ.get("DYN_CPU_BASELINE_THREADS", 16)))  # a 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(cores)
-    model = SCConformerXLRef(vocab_size=a.vocab, seed=0, blank_bias=a.blank_bias)
+    model = SCConformerXLRef(vocab_size=a.vocab, seed=0, blank_bias=0.0)
+    model.load_state_dict({k: v.cpu() for k, v in hip_model.state_dict().items()})    # exactly the weights the HIP path runs
     tok = SyntheticTokenizer(a.vocab)
-    spec = synthetic_spec(a.seq_len * a.cpu_windows, seed=1234)
-    t0 = time.time()
-    for w in range(a.cpu_windows):
+    n_win = a.cpu_windows + 1
+    spec = synthetic_spec(a.seq_len * n_win, seed=1234)
+    mg = torch.Generator().manual_seed(99)
+    masks = [{0: (draw_masks(6, 34, 80, mg), ([], []))} for _ in range(n_win)]
+    outs, times = [], []
+    for w in range(n_win):
         win = spec[:, :, w * a.seq_len:(w + 1) * a.seq_len]
-        dynamic_eval_ref(model, win, a.seq_len, 0, tok, MADGRAD, {'lr': a.lr},
-                         {'n_freq_masks': 6, 'freq_mask_param': 34}, epochs=1, online=False)
-    dt = (time.time() - t0) / a.cpu_windows
+        t0 = time.time()
+        outs.append(dynamic_eval_ref(model, win, a.seq_len, 0, tok, MADGRAD, {'lr': a.lr}, {}, epochs=1, online=False, fixed_masks=masks[w]))
+        times.append(time.time() - t0)
+    timed = times[1:]
+    dt = sum(timed) / len(timed)
     n_windows = 169
-    return {"value": round(3600.0 / (n_windows * dt), 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "sample": f"{a.cpu_windows} of {n_windows} windows (16384 frames each: B=2 forward + CTC + backward + MADGRAD, then "
-                      f"final-pass forward + stitch) on {cores} host threads, {dt:.1f} s/window, extrapolated x{n_windows}"}
+    base = {"value": round(3600.0 / (n_windows * dt), 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "seconds_per_window": [round(t, 2) for t in timed], "spread": round((max(timed) - min(timed)) / dt, 3),
+            "sample": f"{len(timed)} of {n_windows} windows after 1 warm-up window (16384 frames each: B=2 forward + CTC + backward + MADGRAD, "
+                      f"then final-pass forward + stitch) on {cores} host threads, mean {dt:.1f} s/window, extrapolated x{n_windows}"}
+    # the same windows through the HIP path
+    worst, mism, frames, min_margin = 0.0, 0, 0, None
+    hyp_h, hyp_o = [], []
+    for w in range(n_win):
+        args = make_args(a)
+        args.spec_augment_fixed_masks = masks[w]
+        win = spec[:, :, w * a.seq_len:(w + 1) * a.seq_len].contiguous().to(dev)
+        got = lib.dynamic_eval(args, hip_model, win, a.seq_len, 0, tok, use_tqdm=False)
+        want = outs[w]
+        worst = max(worst, float(np.abs(got - want).max()))
+        bad = got.argmax(-1) != want.argmax(-1)
+        frames += bad.size
+        if bad.any():
+            top2 = np.sort(want[bad], -1)[:, -2:]
+            m = float((top2[:, 1] - top2[:, 0]).max())
+            min_margin = m if min_margin is None else max(min_margin, m)
+            mism += int(bad.sum())
+        hyp_h.append(tok.decode(greedy_ctc_ids(torch.from_numpy(got), a.vocab)))
+        hyp_o.append(tok.decode(greedy_ctc_ids(torch.from_numpy(want), a.vocab)))
+    parity = {"max_abs_dlogp": float(f"{worst:.3e}"), "argmax_equal": mism == 0, "argmax_mismatch_frames": mism, "frames": frames,
+              "largest_oracle_margin_at_a_mismatch": min_margin, "windows": n_win,
+              "wer_counters_hip_vs_oracle": list(edit_counts(hyp_h, hyp_o)),
+              "what": "adapted + stitched log-probs of the cpu_baseline windows: HIP path vs CPU oracle, same weights and SpecAugment masks; "
+                      "wer_counters = (ins, del, sub, words) of the HIP transcripts against the oracle's"}
+    return base, parity
 
 
 def main():
@@ -131,7 +198,6 @@ def main():
     from dynamic_asr_eval_amd.model import SCConformerXL
     from dynamic_asr_eval_amd.synthetic_weights import init_synthetic
     from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
-    from dynamic_asr_eval_amd.wer import edit_counts
 
     rank, local_rank, world = ddist.init()
     assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
@@ -144,7 +210,8 @@ def main():
         init_synthetic(m, seed=0, blank_bias=0.0)
         models.append(m)
     model = models[0]
-    tok = SyntheticTokenizer(a.vocab)
+    plain_tok = SyntheticTokenizer(a.vocab)
+    tok = SubstituteLabelTokenizer(plain_tok, a.label_tokens) if a.label_tokens > 0 else plain_tok
     args = make_args(a)
     n_frames = int(a.seconds * 100)
     torch.manual_seed(1234 + rank)
@@ -155,12 +222,23 @@ def main():
 
     decoder = GreedyCTCDecoder(tok, blank_id=a.vocab, device=dev)
 
-    def run_many(spec_list):
+    def run_many(spec_list, tokenizer=None, pcie=None):
         """`n_chains` recordings in flight: one stream + one model replica each, advanced round-robin by one host thread."""
-        outs = lib.dynamic_eval_many(args, models, spec_list, a.seq_len, a.overlap, tok, use_tqdm=False, return_device=not a.pcie)
-        if a.pcie:   # the reference's contract: np.float32 [T_ds, V+1] back on the host (lib.py:640), decoded from there
+        pcie = a.pcie if pcie is None else pcie
+        outs = lib.dynamic_eval_many(args, models[:max(1, min(len(models), len(spec_list)))], spec_list, a.seq_len, a.overlap, tokenizer or tok,
+                                     use_tqdm=False, return_device=not pcie)
+        if pcie:   # the reference's contract: np.float32 [T_ds, V+1] back on the host (lib.py:640), decoded from there
             return [decoder.ids(torch.from_numpy(o).to(dev)) for o in outs]
         return [decoder.ids(o) for o in outs]
+
+    def timed(spec_list, pcie=None, **kw):
+        if pcie:                                      # host-resident inputs are prepared outside the timed region
+            spec_list = [sp if not sp.is_cuda else sp.cpu().pin_memory() for sp in spec_list]
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        run_many(spec_list, pcie=pcie, **kw)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t
 
     specs = [one_step(i) for i in range(a.warmup + a.steps)]
     if a.blank_bias < 0:  # shape the seeded model so pseudo-labels have a speech-like token rate (outside the timed region)
@@ -175,7 +253,7 @@ def main():
         while time.perf_counter() < t_end:
             run_many(specs[:1] * n_chains)
     if a.warmup:
-        run_many(specs[:a.warmup] * n_chains)                                  # every chain (stream, workspace) is warmed
+        run_many(specs[:a.warmup])              # W untimed steps (every chain's stream and workspace was already warmed by the prewarm)
     ddist.barrier()
     torch.cuda.synchronize(dev)
     # Live roofline sampling.  Graph replays cannot be timed per launch, so every WEVERY-th window step of the timed region
@@ -193,8 +271,19 @@ def main():
     if os.environ.get("DYN_DEBUG_HOST"):
         print(f"[host] wall {dt:.3f} s, blocked on pseudo-label ids {lib.HOST_WAIT[0]:.3f} s (incl. warm-up)", file=sys.stderr)
     dt = ddist.max_over_ranks(dt)
-    # the path's one collective: WER counters over RCCL (outside the timed region, as in the reference harness)
-    counts = ddist.all_reduce_counts(edit_counts([tok.decode(h) for h in hyps], [tok.decode(h) for h in hyps]))
+    # the path's one collective (outside the timed region, as in the reference harness): hypothesis token counts over RCCL
+    tokens_total = ddist.all_reduce_counts((sum(len(h) for h in hyps), len(hyps), 0, 0))
+    # side measurements on rank 0 at N = 1 (untimed as far as `value` goes): the model's own collapsing pseudo-labels, and the
+    # boundary-faithful rate (host spectrogram in, numpy log-probs out, decoded from the host copy: reference lib.py:549,640)
+    side = {}
+    n_side = n_chains if a.side_steps < 0 else a.side_steps
+    if world == 1 and n_side > 0:
+        sl = specs[a.warmup:a.warmup + min(n_side, a.steps)]
+        if a.label_tokens > 0:
+            side["value_degenerate_labels"] = round(a.seconds * len(sl) / timed(sl, tokenizer=plain_tok), 3)
+        if not a.pcie:
+            side["value_boundary"] = round(a.seconds * len(sl) / timed(sl, pcie=1), 3)
+        side["side_sample"] = f"{len(sl)} recordings each, same chains, after the timed region"
 
     if rank == 0:
         audio_s = a.seconds * a.steps * world
@@ -232,10 +321,14 @@ def main():
                                      "hipGraphs); `achieved` = launches timed with the other chains drained (kernel's own duration), "
                                      "`achieved_shared` = launches timed while the other chains share the GPU"
                                      if a.graphs else "every 4th GEMM launch"},
-            "wer_counters": list(counts),
+            "hyp_tokens_total": int(tokens_total[0]),
         }
+        out.update(side)
+        out["config"]["label_tokens_per_window"] = a.label_tokens
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a)
+            for m in models:                                           # the parity leg runs on the bench's own (restored) weights
+                m.use_graphs = bool(a.graphs)
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(a, model, dev)
         print(json.dumps(out), flush=True)
 
 

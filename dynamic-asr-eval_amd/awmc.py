@@ -58,14 +58,14 @@ def AWMC(args, model, spec, seq_len, overlap, tokenizer, use_tqdm=True, optim=MA
     fs = lib.get_frame_shuffle_config_from_args(args)
     if fs['time_dimension'] or fs['freq_dimension']:
         lib._unsupported("frame_shuffle")
-    if args.__dict__.get('bitfit', False):
-        lib._unsupported("bitfit")
     device = model.device
     spec_n = spec.shape[-1]
     downsampling_factor = args.config['model']['subsampling_factor']
     seq_len = seq_len if seq_len != -1 else args.config['audio_chunking']['size']
     original_flat = model.flat_params.clone()
     frozen_before = set(model.frozen)
+    if args.__dict__.get('bitfit', False):                          # reference lib.py:234-235
+        lib.bitfit(model)
     if args.__dict__.get('freeze_subsampling', False):
         lib.freeze_subsampling(model)
     if args.__dict__.get('freeze_all_but_last_block_and_head', False):

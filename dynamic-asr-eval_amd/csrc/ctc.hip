@@ -18,7 +18,8 @@
 namespace {
 
 constexpr int SCAN_T = 1024;  // threads of the serial scan workgroup
-constexpr int PD = 8;         // slab prefetch distance (time steps)
+template <int ITEMS> struct ScanCfg { static constexpr int PD = ITEMS >= 8 ? 2 : ITEMS >= 4 ? 4 : 8; };   // slab prefetch distance (time steps): 8 deep
+// while it fits the 128 VGPRs of a 1024-thread workgroup; ITEMS x PD ring registers at ITEMS >= 4 would spill to scratch at 8
 
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
@@ -145,6 +146,7 @@ __device__ __forceinline__ void ctc_alpha_body(float* rows, const float* __restr
     float* al = alpha + b * d.T_max * d.L_max;
     float* prev = rows;
     float* cur = rows + d.L_max;
+    constexpr int PD = ScanCfg<ITEMS>::PD;
     bool skip[ITEMS];
     float ring[ITEMS][PD];
 #pragma unroll
@@ -213,6 +215,7 @@ __device__ __forceinline__ void ctc_beta_body(float* rows, const float* __restri
     float* al = alpha + b * d.T_max * d.L_max;
     float* prev = rows;
     float* cur = rows + d.L_max;
+    constexpr int PD = ScanCfg<ITEMS>::PD;
     bool skip[ITEMS];
     float ring[ITEMS][PD];
 #pragma unroll
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
                                                         int64_t g_sb, float grad_scale, int mean_reduction, CtcDims d) {
     __shared__ float red[8];
     const int64_t t = blockIdx.x, b = blockIdx.y;
-    const int T = ilen[b], S = tlen[b], L = 2 * S + 1;
+    const int T = ilen[b], S = tlen[b];
     float* gr = grad + t * g_st + b * g_sb;
     if (t >= T) {  // padded frames get zero gradient
         for (int c = threadIdx.x; c < d.C; c += blockDim.x) gr[c] = 0.f;

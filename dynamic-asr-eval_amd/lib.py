@@ -104,6 +104,20 @@ def _set_frozen(model, prefixes=None, only=None):
     return model
 
 
+def bitfit(model):
+    """reference lcasr/lib.py:148-160: freeze everything, then train only the biases of LayerNorm / Linear / BatchRenorm modules.
+    Upstream module classes are not visible (un-vendored), so the mapping onto this package's parameter names is: every
+    `*norm*.bias` (block, module and decoder LayerNorms, the conv-module norm when it has a bias) and the biases of the Linear
+    layers (`attn.qkv`, `attn.out`, `subsampling.out`, `decoder.ff`, `decoder.reproj`); convolution biases (depthwise and
+    pointwise convs are Conv modules upstream, not nn.Linear) stay frozen like the weights."""
+    if not hasattr(model, "frozen"):
+        raise ops.DynError("bitfit: only the HIP SCConformerXL is supported")
+    linear_bias = ("attn.qkv.bias", "attn.out.bias", "subsampling.out.bias", "decoder.ff.bias", "decoder.reproj.bias")
+    train = {n for n, _ in model.spec if n.endswith(".bias") and ("norm" in n.rsplit(".", 2)[-2] or n.endswith(linear_bias))}
+    model.frozen = {n for n, _ in model.spec if n not in train}
+    return model
+
+
 def freeze_subsampling(model):
     if getattr(model, 'subsampling', None) is None:
         print('No subsampling module found to freeze')
@@ -281,6 +295,11 @@ def _dynamic_eval_gen(
     for epoch in range(args.__dict__.get('epochs', 1)):
         if verbose:
             print(f'Epoch {epoch + 1} / {epochs}')
+        if online and epoch > 0:
+            # the reference's loop runs range(args.epochs) even in online mode (lib.py:527) and every epoch overwrites
+            # model_outputs[i] (lib.py:589): only the last epoch's posteriors are stitched
+            acc.zero_(); cnt.zero_()
+            stitch["pos"] = stitch["end"] = 0
         training_keys = list(training_data.keys())
         training_keys = random.sample(training_keys, len(training_keys)) if shuffle else training_keys
         epochs_stime = time.time()

@@ -29,11 +29,27 @@ DEFAULT_CONFIG = dict(
 )
 
 
+# Keys of the reference yaml (earnings_finetune/lcasr160rb1.yaml:1-29) that select an architecture VARIANT upstream.  This
+# implementation builds exactly one variant; a checkpoint config asking for another must not be run silently as this one.
+SUPPORTED_VARIANT = dict(
+    bias_in_ff=False, qk_rms_norm=False, sandwich_norm=False, default_norm="layer_norm", use_rotary=True, encoder_mode="conformer",
+    decoder_norm=True, gated_sc=False, self_condition_subsampling=False, subsampling_norm_out=False, shift_kvs=False,
+    subsampling="dw_striding", subsampling_act="silu",
+)
+# yaml keys that do not change the arithmetic of the eval path (dropout is off in eval mode; flash attention is an implementation choice)
+IGNORED_KEYS = {"dropout_ff", "dropout_conv", "dropout_attn", "flash_attn", "checkpoint_every_n_layers"}
+
+
 def make_config(**over):
     cfg = dict(DEFAULT_CONFIG)
     for k, v in over.items():
         if k in DEFAULT_CONFIG:
             cfg[k] = v
+        elif k in SUPPORTED_VARIANT:
+            if v != SUPPORTED_VARIANT[k]:
+                raise ValueError(f"model config {k}={v!r}: this implementation supports only {k}={SUPPORTED_VARIANT[k]!r}")
+        elif k not in IGNORED_KEYS:
+            raise ValueError(f"unknown model config key {k!r} (known: {sorted(DEFAULT_CONFIG) + sorted(SUPPORTED_VARIANT)})")
     return cfg
 
 
@@ -148,7 +164,7 @@ class SCConformerXL:
         return sd
 
     def load_state_dict(self, sd, strict=True):
-        missing = [n for n, _ in self.spec if n not in sd]
+        missing = [n for n, _ in self.spec if n not in sd] + [n for n in self.buffers if n not in sd]
         unexpected = [n for n in sd if n not in self.P and n not in self.buffers]
         if strict and (missing or unexpected):
             raise KeyError(f"missing {missing[:5]}… unexpected {unexpected[:5]}…")
@@ -195,8 +211,8 @@ class SCConformerXL:
         """Accumulates dW (and db) for y = x @ W^T + b and returns alpha * dy @ W (or None)."""
         if self.trainable(wname) and not self._skip_wgrad:
             ops.linear_wgrad(dy, x, self.G[wname], alpha=alpha, beta=1.0)
-            if bname is not None:
-                ops.colsum(dy, self.G[bname], beta=1.0)
+        if bname is not None and self.trainable(bname) and not self._skip_wgrad:    # bitfit trains a bias under a frozen weight
+            ops.colsum(dy, self.G[bname], beta=1.0)
         return ops.linear_dgrad(dy, self.P[wname], alpha=alpha) if need_dx else None
 
     # ------------------------------------------------------------------ forward

@@ -52,7 +52,15 @@ def load_model_and_tokenizer(args, device):
     model = SCConformerXL(dict(config['model']), vocab_size=tokenizer.vocab_size(), device=device)
     model.print_total_params()
     if state is not None:
-        model.load_state_dict(state, strict=False)
+        res = model.load_state_dict(state, strict=False)            # reference :47 (strict=False)
+        # Parameter names are this package's (the upstream module is un-vendored): a checkpoint that matches nothing would leave
+        # the zero-initialised flat buffer in place and still print a WER.  Refuse unless explicitly allowed.
+        if res.missing_keys or res.unexpected_keys:
+            msg = (f'checkpoint {args.checkpoint}: {len(res.missing_keys)} parameters/buffers of the model are missing '
+                   f'(e.g. {res.missing_keys[:3]}), {len(res.unexpected_keys)} checkpoint keys are unknown (e.g. {res.unexpected_keys[:3]})')
+            if res.missing_keys and not args.__dict__.get('allow_missing', False):
+                raise KeyError(msg + '; pass `-kwargs allow_missing=True` to run with the missing tensors left at zero')
+            print('WARNING: ' + msg)
         print(f'Loaded model from {args.checkpoint}')
     else:
         from .synthetic_weights import init_synthetic

@@ -50,6 +50,10 @@ def replicate(model, n):
     for _ in range(max(0, n - 1)):
         m = SCConformerXL(dict(model.config), vocab_size=model.decoder.num_classes - 1, device=model.device)
         m.flat_params.copy_(model.flat_params)
+        for name, buf in model.buffers.items():      # batch_renorm running statistics: part of the model, not of flat_params
+            m.buffers[name].copy_(buf)
+        m.frozen = set(model.frozen)
+        m.fused_attention, m.fused_convmod = model.fused_attention, model.fused_convmod
         m.eval()
         out.append(m)
     return out

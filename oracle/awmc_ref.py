@@ -39,10 +39,29 @@ class EMARef:
                     p.copy_(s)
 
 
+def bitfit_ref(model):
+    """reference lcasr/lib.py:148-160: requires_grad False everywhere, then True for the biases of LayerNorm / Linear /
+    BatchRenorm modules.  On the oracle's module tree (oracle/conformer_ref.py): `_Norm` of kind layer_norm / batch_renorm, and
+    the `_Lin` modules that are nn.Linear upstream (attn.qkv, attn.out, subsampling.out, decoder.ff, decoder.reproj; the
+    pointwise convolutions of the conv module and of the subsampling are Conv modules upstream)."""
+    for p in model.parameters():
+        p.requires_grad = False
+    linear = ("attn.qkv", "attn.out", "subsampling.out", "decoder.ff", "decoder.reproj")
+    for name, module in model.named_modules():
+        cls = type(module).__name__
+        if cls == "_Norm" and module.bias is not None:
+            module.bias.requires_grad = True
+        if cls == "_Lin" and module.bias is not None and name.endswith(linear):
+            module.bias.requires_grad = True
+    return model
+
+
 def awmc_ref(model, spec, seq_len, overlap, tokenizer, optimizer_cls, lr_args, spec_augment_config, epochs=1, ema_decay=0.999,
-             downsampling_factor=8, fixed_masks=None, return_params=False):
+             downsampling_factor=8, fixed_masks=None, return_params=False, bitfit=False):
     spec_n = spec.shape[-1]
     original = [p.clone().detach().cpu() for p in model.parameters()]
+    if bitfit:                                            # reference lib.py:234-235
+        bitfit_ref(model)
     model.train()
     ema_leader = EMARef(model.parameters(), ema_decay); ema_leader.update()
     ema_anchor = EMARef(model.parameters(), 1.0); ema_anchor.update()
@@ -114,5 +133,6 @@ def awmc_ref(model, spec, seq_len, overlap, tokenizer, optimizer_cls, lr_args, s
         updated = [p.clone().detach().cpu() for p in model.parameters()]
     for p, po in zip(model.parameters(), original):
         p.data = po.data.to(p.device)
+        p.requires_grad = True
     out = logits.squeeze(0).numpy().astype(np.float32)
     return (out, updated) if return_params else out

@@ -118,13 +118,14 @@ def dynamic_eval_ref(model, spec, seq_len, overlap, tokenizer, optimizer_cls, lr
     assert overlap / downsampling_factor == overlap // downsampling_factor
     all_logits = torch.zeros((1, spec_n // 4 + seq_len, tokenizer.vocab_size() + 1))
     logit_count = torch.zeros((1, spec_n // 4 + seq_len, tokenizer.vocab_size() + 1))
-    epochs = 1 if online else epochs
+    loop_epochs = epochs                   # the reference's loop runs `range(args.epochs)` (lib.py:527) ...
+    epochs = 1 if online else epochs       # ... although the printed count is forced to 1 in online mode (lib.py:515)
     shuffle = False if online else shuffle
-    model_outputs = {}
+    model_outputs = {}                     # online: overwritten by every epoch, so the LAST epoch is what gets stitched (lib.py:583-589)
     model.eval()
     training_data, training_keys = prepare_chunks(spec, seq_len, overlap)
     n_done = 0
-    for epoch in range(epochs):
+    for epoch in range(loop_epochs):
         training_keys = list(training_data.keys())
         training_keys = random.sample(training_keys, len(training_keys)) if shuffle else training_keys
         for i in training_keys:

@@ -1,0 +1,148 @@
+"""Oracle parity AT THE BASELINE CONFIG-2 SHAPE (SCConformerXL 6 x 768, 6 heads x 128, V+1 = 4096, one 16384-frame window ->
+T' = 2048): the adapt step of reference lcasr/lib.py:538-581 (B = 2 grad-mode forward, greedy pseudo-label, CTC loss / (N*B),
+backward, one MADGRAD step) and a B = 4 no-grad forward of the final pass (lib.py:594-612; takes the fused attention kernel)
+against oracle/conformer_ref.py + torch.nn.CTCLoss + oracle/madgrad_ref.py on the CPU with the same seeded weights, the same
+window and the same stored SpecAugment masks.  This is the only place where the autotuned GEMM table (csrc/gemm_tuned.inc),
+split-K / tail-slicing plans, the fused attention and the 4-frame convmod tiling meet the oracle (the small-config tests use
+other plans).  Bars (BASELINE.json): log-probs within 1e-3, argmax ids bit-exact, plus per-parameter gradients within 2e-3
+relative and the updated parameters within 5e-5.
+Argmax: a frame whose top-2 margin in the ORACLE is below 5e-5 (under the fp32 summation-order noise of either side) cannot be
+asked to agree; such frames are counted and must be rare, every other frame must match bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+VOCAB, SEQ = 4095, 16384
+MARGIN = 5e-5
+
+
+def _argmax_check(hip_lp, ref_lp, what):
+    a, b = hip_lp.argmax(-1), ref_lp.argmax(-1)
+    bad = (a != b)
+    top2 = ref_lp.topk(2, -1).values
+    margin = top2[..., 0] - top2[..., 1]
+    assert not (bad & (margin >= MARGIN)).any(), f"{what}: argmax differs at a frame with oracle margin >= {MARGIN}"
+    n_bad = int(bad.sum())
+    assert n_bad <= max(2, a.numel() // 2000), f"{what}: {n_bad} near-tie frames differ"
+    return n_bad
+
+
+@pytest.fixture(scope="module")
+def pair(cuda):
+    from oracle.conformer_ref import SCConformerXLRef
+    from dynamic_asr_eval_amd.model import SCConformerXL
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = SCConformerXLRef(vocab_size=VOCAB, seed=0, blank_bias=1.34)
+    hip = SCConformerXL(vocab_size=VOCAB, device=cuda)
+    hip.load_state_dict(ref.state_dict())
+    return ref, hip
+
+
+def test_full_size_adapt_step_and_final_pass_match_the_oracle(cuda, pair):
+    from oracle import dynamic_eval_ref as R
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import ops
+    from dynamic_asr_eval_amd.datasets import synthetic_spec
+    from dynamic_asr_eval_amd.optim import MADGRAD
+    ref, hip = pair
+    blank = VOCAB
+    spec = synthetic_spec(SEQ + 3 * 2048, seed=77)                       # 4 overlapping windows for the final pass
+    win = spec[:, :, :SEQ]
+    masks = (R.draw_masks(6, 34, 80, torch.Generator().manual_seed(9)), ([], []))
+    chunk = win.repeat(2, 1, 1).clone()
+    R.apply_masks(chunk[0], masks, zero_masking=False)                    # copy 0 augmented, copy -1 clean (lib.py:541)
+
+    # ---------------- oracle: adapt step
+    ref.eval()
+    opt_ref = MADGRAD_REF(ref.parameters(), lr=9e-5)
+    out_ref = ref(audio_signal=chunk)['final_posteriors']
+    ids = R.greedy_ctc_ids(out_ref[-1].detach(), blank)
+    assert 5 <= len(ids) <= 2040, f"pseudo-label length {len(ids)}: the seeded model should decode a non-degenerate transcript"
+    tgt = torch.LongTensor(ids)[None]
+    N = out_ref.shape[1]
+    loss_ref = torch.nn.CTCLoss(blank=blank, reduction='sum')(out_ref[:1].transpose(0, 1), tgt, torch.LongTensor([N]),
+                                                               torch.LongTensor([len(ids)])) / N
+    opt_ref.zero_grad()
+    loss_ref.backward()
+    grads_ref = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    opt_ref.step()
+
+    # ---------------- HIP: the same step through the C-ABI
+    hip.eval()
+    hip.use_graphs = False
+    opt = MADGRAD(hip.parameters(), lr=9e-5)
+    with torch.enable_grad():
+        out = hip(audio_signal=chunk.to(cuda))['final_posteriors']
+    lp, lp_ref = out.cpu(), out_ref.detach()
+    err_fwd = (lp - lp_ref).abs().max().item()
+    assert err_fwd < 1e-3, f"forward log-probs differ by {err_fwd}"
+    near = _argmax_check(lp, lp_ref, "adapt-step forward")
+    ids_dev, n_dev = ops.ctc_greedy(out[-1].detach(), blank)
+    ids_hip = ids_dev[0, :int(n_dev[0])].cpu().tolist()
+    if near == 0:
+        assert ids_hip == ids, "greedy pseudo-label ids differ from the oracle's"
+    targets = torch.tensor([ids], dtype=torch.int32, device=cuda)
+    ilen = torch.full((1,), N, dtype=torch.int32, device=cuda)
+    tlen = torch.full((1,), len(ids), dtype=torch.int32, device=cuda)
+    loss, _, g_aug = ops.ctc_loss(out[:1].contiguous(), targets, ilen, tlen, blank, reduction="sum", grad_scale=1.0 / N)
+    assert abs(float(loss.item()) / N - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref))), (float(loss.item()) / N, float(loss_ref))
+    opt.zero_grad()
+    hip.backward(g_aug, n_active=1)
+    worst_g, worst_name = 0.0, ""
+    for (n, _), gh in zip(hip.named_parameters(), hip.grads()):
+        gr = grads_ref[n]
+        rel = (gh.cpu() - gr).abs().max().item() / (gr.abs().max().item() + 1e-20)
+        if rel > worst_g:
+            worst_g, worst_name = rel, n
+    assert worst_g < 2e-3, f"gradient of {worst_name}: relative error {worst_g}"
+    opt.step()
+    worst_p = max((p.cpu() - q.detach()).abs().max().item() for (_, p), (_, q) in zip(hip.named_parameters(), ref.named_parameters()))
+    assert worst_p < 5e-5, f"updated parameters differ by {worst_p}"
+
+    # ---------------- final pass with the adapted weights: B = 4 no-grad forward (fused attention on the HIP side)
+    batch = torch.cat([spec[:, :, k * 2048:k * 2048 + SEQ] for k in range(4)], 0).contiguous()
+    with torch.no_grad():
+        fin_ref = ref(audio_signal=batch)['final_posteriors']
+        hip.fused_attention = True
+        fin = hip(audio_signal=batch.to(cuda))['final_posteriors'].cpu()
+    err_fin = (fin - fin_ref).abs().max().item()
+    assert err_fin < 1e-3, f"final-pass log-probs differ by {err_fin}"
+    near_fin = _argmax_check(fin, fin_ref, "final pass")
+    print(f"full-size parity: |dlogp| fwd {err_fwd:.2e}, worst grad rel {worst_g:.2e} ({worst_name}), |dparam| {worst_p:.2e}, "
+          f"final pass {err_fin:.2e}; near-tie frames {near}+{near_fin}; pseudo-label tokens {len(ids)}")
+
+
+def test_every_tuned_gemm_shape_matches_float64(cuda):
+    """Walks csrc/gemm_tuned.inc (the autotuned (tile, split-K, tail-slice) plan per GEMM shape of the step; make_plan looks the
+    shape up, so calling the GEMM with that shape runs that plan) and checks a sample of output rows/columns against a float64
+    product of the same operands.  fp32 MFMA accumulation over K <= 8192: relative error of a dot product ~ sqrt(K) * 2^-24."""
+    import os
+    import re
+    from dynamic_asr_eval_amd import ops
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dynamic-asr-eval_amd", "csrc", "gemm_tuned.inc")
+    rows = [tuple(int(v) for v in m.groups()) for m in
+            re.finditer(r"\{\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)\s*\}", open(inc).read())]
+    assert len(rows) >= 50, f"expected the tuned table, parsed {len(rows)} rows"
+    g = torch.Generator().manual_seed(2024)
+    worst = 0.0
+    for ta, tb, M, N, K, batch, bm, bn, split, tail in rows:
+        a = (torch.rand((batch, K, M) if ta else (batch, M, K), generator=g) - 0.5).to(cuda)
+        b = (torch.rand((batch, N, K) if tb else (batch, K, N), generator=g) - 0.5).to(cuda)
+        c = torch.full((batch, M, N), float("nan"), device=cuda)
+        ops.gemm(a, b, c, trans_a=bool(ta), trans_b=bool(tb), M=M, N=N, K=K, lda=a.shape[2], ldb=b.shape[2], ldc=N, nb1=batch,
+                 sa=(a.shape[1] * a.shape[2], 0), sb=(b.shape[1] * b.shape[2], 0), sc=(M * N, 0))
+        assert torch.isfinite(c).all(), f"unwritten outputs for {(ta, tb, M, N, K, batch)}"
+        ri = torch.unique(torch.cat([torch.tensor([0, M - 1, M // 2]), torch.randint(0, M, (13,), generator=g)])).to(cuda)
+        ci = torch.unique(torch.cat([torch.tensor([0, N - 1, N // 2]), torch.randint(0, N, (13,), generator=g)])).to(cuda)
+        ad = (a.transpose(1, 2) if ta else a).double()      # [batch, M, K]
+        bd = (b.transpose(1, 2) if tb else b).double()      # [batch, K, N]
+        want_rows = ad[:, ri] @ bd                            # [batch, |ri|, N]
+        want_cols = ad @ bd[:, :, ci]                         # [batch, M, |ci|]
+        scale = max(want_rows.abs().max().item(), 1e-6)
+        err = max((c[:, ri].double() - want_rows).abs().max().item(), (c[:, :, ci].double() - want_cols).abs().max().item()) / scale
+        worst = max(worst, err)
+        assert err < 2e-5, f"GEMM {(ta, tb, M, N, K, batch)} plan {(bm, bn, split, tail)}: relative error {err}"
+        del a, b, c, ad, bd
+    print(f"{len(rows)} tuned shapes, worst relative error {worst:.2e}")

@@ -153,6 +153,80 @@ def test_awmc_parity(cuda):
         assert (a - b).abs().max().item() < 5e-5
 
 
+def test_awmc_bitfit_parity(cuda):
+    """`-kwargs bitfit=True` (reference lcasr/lib.py:148-160,234-235): only norm / linear biases move; every other parameter
+    comes back bit-identical, and the moved ones match the oracle."""
+    from oracle.awmc_ref import awmc_ref
+    from oracle import dynamic_eval_ref as R
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    cfg = dict(SMALL, conv_norm="layer_norm")
+    ref, hip = _pair(cuda, cfg, vocab=128, seed=19, blank_bias=1.5)
+    tok = SyntheticTokenizer(128)
+    spec = torch.randn(1, 80, 900, generator=torch.Generator().manual_seed(23))
+    _, keys = R.prepare_chunks(spec, 512, 256)
+    masks = _masks_for(keys, 80, None, seed=8)
+    before = {n: p.clone() for n, p in hip.named_parameters()}
+    out_ref, p_ref = awmc_ref(ref, spec, 512, 256, tok, MADGRAD_REF, {'lr': 1e-3}, {}, epochs=1, fixed_masks=masks, return_params=True, bitfit=True)
+    args = _args(optim_lr=1e-3, epochs=1, bitfit=True, spec_augment_fixed_masks=masks, quiet=True)
+    out, p = lib.AWMC(args, hip, spec, 512, 256, tok, use_tqdm=False, return_params=True)
+    assert hip.frozen == set() and all(torch.equal(q, before[n]) for n, q in hip.named_parameters())
+    assert out.shape == out_ref.shape and np.abs(out - out_ref).max() < 1e-3 and np.array_equal(out.argmax(-1), out_ref.argmax(-1))
+    moved = 0
+    for (n, _), a, b in zip(hip.named_parameters(), p, p_ref):
+        assert (a - b).abs().max().item() < 5e-5, n
+        changed = not torch.equal(a, before[n].cpu())
+        is_bitfit_bias = n.endswith(".bias") and ("norm" in n.split(".")[-2] or n.endswith(("qkv.bias", "attn.out.bias", "subsampling.out.bias",
+                                                                                                 "decoder.ff.bias", "decoder.reproj.bias")))
+        assert changed == is_bitfit_bias or (is_bitfit_bias and not changed and a.abs().max() == 0), (n, changed)
+        moved += changed
+    assert moved >= 10
+
+
+def test_chains_replicas_carry_buffers_and_frozen_set(cuda):
+    """run_seq_eval.replicate(): the replicas of a batch_renorm model must carry its running statistics (they live outside
+    flat_params) and its frozen set; two recordings in flight then reproduce the one-at-a-time outputs bit for bit."""
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.run_seq_eval import replicate
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    cfg = dict(SMALL, conv_norm="batch_renorm")
+    ref, hip = _pair(cuda, cfg, vocab=128, seed=4, blank_bias=1.5)
+    g = torch.Generator().manual_seed(77)
+    for n in hip.buffers:
+        hip.buffers[n].copy_((torch.rand(hip.buffers[n].shape, generator=g) * (2.0 if n.endswith("var") else 0.6) + (0.5 if n.endswith("var") else -0.3)).to(cuda))
+    hip.frozen = {"subsampling."}
+    models = replicate(hip, 2)
+    assert all(torch.equal(models[1].buffers[n], hip.buffers[n]) for n in hip.buffers) and models[1].frozen == hip.frozen
+    tok = SyntheticTokenizer(128)
+    specs = [torch.randn(1, 80, n, generator=g) for n in (1100, 900)]
+    args = _args(optim_lr=1e-4, epochs=1, quiet=True, spec_augment_n_freq_masks=0)
+    one = [lib.dynamic_eval(args, hip, sp, 512, 256, tok, use_tqdm=False) for sp in specs]
+    two = lib.dynamic_eval_many(args, models, specs, 512, 256, tok, use_tqdm=False)
+    assert all(np.array_equal(a, b) for a, b in zip(one, two))
+    hip.frozen = set()
+
+
+@pytest.mark.parametrize("epochs", [2, 3])
+def test_online_mode_with_several_epochs_stitches_the_last_one(cuda, epochs):
+    """online=True with epochs > 1: the reference's loop still runs range(args.epochs) (lcasr/lib.py:527; only the printed count is
+    forced to 1, :515) and every epoch overwrites model_outputs[i] (:583-589), so the weights adapt over all epochs and the LAST
+    epoch's posteriors are stitched: the output must neither double in length nor overflow the accumulator."""
+    from oracle import dynamic_eval_ref as R
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    ref, hip = _pair(cuda, SMALL, vocab=128, seed=15, blank_bias=1.5)
+    tok = SyntheticTokenizer(128)
+    spec = torch.randn(1, 80, 1100, generator=torch.Generator().manual_seed(5))
+    _, keys = R.prepare_chunks(spec, 512, 256)
+    masks = _masks_for(keys, 80, None, seed=2)
+    out_ref = R.dynamic_eval_ref(ref, spec, 512, 256, tok, MADGRAD_REF, {'lr': 1e-4}, {}, epochs=epochs, online=True, fixed_masks=masks)
+    args = _args(optim_lr=1e-4, epochs=epochs, online=True, spec_augment_fixed_masks=masks, quiet=True)
+    out = lib.dynamic_eval(args, hip, spec, 512, 256, tok, use_tqdm=False)
+    assert out.shape == out_ref.shape and np.abs(out - out_ref).max() < 1e-3 and np.array_equal(out.argmax(-1), out_ref.argmax(-1))
+
+
 def test_adapt_on_concat_only_matches_loop_a(cuda):
     """run_half_concat_eval.adapt_on_concat_only (reference :64-160) = Loop A of dynamic eval on the concatenation."""
     from oracle import dynamic_eval_ref as R
