@@ -122,7 +122,7 @@ class SubstituteLabelTokenizer:
         return self.base.encode(self.text)
 
 
-def cpu_baseline_and_parity(a, hip_model, dev):
+def cpu_baseline(a, hip_model, dev):
     """CPU oracle (oracle/dynamic_eval_ref.py + oracle/conformer_ref.py) on a bounded sample: one untimed warm-up window, then
     `cpu_windows` full 16384-frame windows, each = adapt step (B=2 fwd + CTC + bwd + MADGRAD) + final-pass forward + stitch; the
     1 h recording is 169 such windows, so audio-s/s = 3600 / (169 * seconds_per_window).
@@ -328,7 +328,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             for m in models:                                           # the parity leg runs on the bench's own (restored) weights
                 m.use_graphs = bool(a.graphs)
-            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(a, model, dev)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(a, model, dev)
         print(json.dumps(out), flush=True)
 
 
