@@ -1,21 +1,27 @@
-"""wav2vec2 harness (BASELINE config 3), shaped after the reference's `wav2vec2/tedlium/run.py:106-175`:
-load model -> split the talk into utterances (`fetch_utterances`, :56-83) -> `lib.dynamic_eval_su` (:155) -> per-utterance
-greedy decode + join (:156-160) -> WER (:169).
+"""wav2vec2 harness (BASELINE config 3) mirroring the reference's two wav2vec2 drivers, same flags (`lib.apply_args`,
+reference wav2vec2/lib.py:477-493), same stdout lines (`Loaded model from`, `Total number of parameters`, `WER:`) and the same
+`-log` line:
+  --mode su       reference wav2vec2/tedlium/run.py:106-175: split the talk into STM utterances (`fetch_utterances`, :56-83) ->
+                  `lib.dynamic_eval_su` (:155) -> per-utterance greedy decode, lower, strip, join (:156-160) -> normalise -> WER (:169)
+  --mode chunked  reference wav2vec2/earnings22/run.py:59-117: `lib.dynamic_eval` over waveform windows (`-seq 131072 -overlap 0`,
+                  :100) -> greedy decode of the stitched log-probs (:103) -> normalise -> WER (:114)
+Like both reference drivers it processes the FIRST recording only (they `break` after it: tedlium/run.py:166, earnings22/run.py:111).
 
-`AutoModelForCTC.from_pretrained("facebook/wav2vec2-base-960h")` and the TEDLIUM files cannot be fetched offline, so this
-harness builds the base architecture (HF `Wav2Vec2Config()` defaults) with seeded weights, or loads a local HF
-state_dict (`-c file.pt`, torch.load(weights_only=True)), and evaluates a synthetic TEDLIUM-shape talk: ~15 min cut into
-utterances of 2-15 s.  Prints `WER:` like the reference and the audio-seconds per second."""
+`AutoModelForCTC.from_pretrained("facebook/wav2vec2-base-960h")` and the corpora cannot be fetched offline, so the harness builds
+the base architecture (HF `Wav2Vec2Config()` defaults: 7 conv layers of 512 channels, positional conv k=128 g=16, 12 x 768, vocab 32)
+with seeded weights, or loads a local HF state_dict (`-c file.pt`, torch.load(weights_only=True)), and evaluates a synthetic
+TEDLIUM-shape talk (`--seconds`, utterances of 2-15 s).  Reported WERs use this package's reduced text
+normaliser (wer.basic_normalize), not whisper's EnglishTextNormalizer (un-vendored)."""
 import argparse
 import time
 
 import torch
 
 from . import wav2vec2_lib as lib
-from .datasets import synthetic_waveform
+from .datasets import synthetic_text, synthetic_waveform
 from .decoding import GreedyCTCDecoder
 from .wav2vec2_model import Wav2Vec2ForCTC
-from .wer import word_error_rate_detail
+from .wer import basic_normalize as normalize, word_error_rate_detail
 
 
 def fetch_utterances_synthetic(total_seconds=900.0, seed=7, sample_rate=16000):
@@ -26,7 +32,8 @@ def fetch_utterances_synthetic(total_seconds=900.0, seed=7, sample_rate=16000):
         d = float(2.0 + 13.0 * torch.rand(1, generator=g).item())
         d = min(d, total_seconds - t) if total_seconds - t > 2.0 else d
         wav = synthetic_waveform(d, seed=seed + len(utts), sample_rate=sample_rate)
-        utts.append({'waveform': wav.unsqueeze(0), 'text': '', 'start': t, 'end': t + d})
+        text = " ".join(w.replace("w", "word") for w in synthetic_text(max(1, int(2.5 * d)), seed + len(utts)).split())
+        utts.append({'waveform': wav.unsqueeze(0), 'text': text, 'start': t, 'end': t + d})
         t += d
     return utts
 
@@ -42,37 +49,68 @@ def init_synthetic(model, seed=0):
         p.copy_(v.to(p.device))
 
 
-def main(args):
-    device = torch.device('cuda', 0)
+def load_pretrained_model(args, device):
+    """reference wav2vec2/lib.py:20-23 (`AutoModelForCTC.from_pretrained`) — offline: local state_dict or seeded weights."""
     model = Wav2Vec2ForCTC(None, device=device)
     if args.checkpoint:
-        model.load_state_dict(torch.load(args.checkpoint, map_location='cpu', weights_only=True), strict=False)
+        res = model.load_state_dict(torch.load(args.checkpoint, map_location='cpu', weights_only=True), strict=False)
+        missing = getattr(res, 'missing_keys', [])
+        if missing:
+            raise KeyError(f'checkpoint {args.checkpoint}: {len(missing)} parameters of the model are missing (e.g. {missing[:3]})')
     else:
         init_synthetic(model, args.seed)
-    tokenizer = lib.CharTokenizer()
-    utterances = fetch_utterances_synthetic(args.seconds, args.seed)
-    a = argparse.Namespace(epochs=args.epochs, shuffle=False)
+    return model, lib.CharTokenizer()
+
+
+def main(args):
+    assert args.split in ['test', 'dev'], f'Split must be either test or dev (got {args.split})'
+    device = torch.device('cuda', 0)
+    model, tokenizer = load_pretrained_model(args, device)
+    print(f'Loaded model from {args.checkpoint}')
+    print(f'Total number of parameters: {sum(p.numel() for p in model.parameters()) / 1e6:.2f}M')
+    model.eval()
+    tokenizer.blank_id = 0
+    decoder = GreedyCTCDecoder(tokenizer=tokenizer, blank_id=tokenizer.blank_id, device=device)
+    utterances = fetch_utterances_synthetic(args.seconds, args.seed + (0 if args.split == 'test' else 1000))
+    gold_text = normalize(" ".join(u['text'] for u in utterances)).lower()
+    all_texts, all_golds = [], []
     torch.cuda.synchronize()
     t0 = time.time()
-    utterances = lib.dynamic_eval_su(a, model, utterances, args.seq_len, args.overlap, tokenizer, None, use_tqdm=False,
-                                     optim=lib.MADGRAD, lr_args={'lr': args.lr})
-    decoder = GreedyCTCDecoder(tokenizer=tokenizer, blank_id=tokenizer.blank_id, device=device)
-    text = " ".join(decoder(u['probs']) for u in utterances)
+    if args.mode == 'su':
+        utterances_out = lib.dynamic_eval_su(args, model, utterances, args.seq_len, args.overlap, tokenizer, None, use_tqdm=False,
+                                             optim=lib.MADGRAD, lr_args={'lr': args.lr})
+        for i, utt in enumerate(utterances_out):
+            utterances_out[i]['text'] = decoder(utt['probs']).lower()
+        text = ' '.join([el['text'].strip() for el in utterances_out])
+    else:
+        audio_spec = torch.cat([u['waveform'] for u in utterances], -1)                     # [1, L] waveform of the whole talk
+        logits = lib.dynamic_eval(args, model, audio_spec, args.seq_len, args.overlap, tokenizer, None, use_tqdm=False,
+                                  optim=lib.MADGRAD, lr_args={'lr': args.lr}, return_device=True)
+        text = decoder(logits).lower()
+    out = normalize(text).lower()
     torch.cuda.synchronize()
     dt = time.time() - t0
-    wer = word_error_rate_detail([text.lower()], [" ".join(u['text'] for u in utterances).lower()])[0]
+    if args.verbose:
+        print(gold_text[:200], '\n', out[:200], '\n\n')
+    all_texts.append(out)
+    all_golds.append(gold_text)
+    wer, words, ins_rate, del_rate, sub_rate = word_error_rate_detail(hypotheses=all_texts, references=all_golds)
     print(f'WER: {wer}')
-    print(f'wav2vec2 dynamic_eval_su: {len(utterances)} utterances, {args.seconds:.0f} s of audio in {dt:.2f} s -> {args.seconds / dt:.1f} audio-s/s')
+    if args.log != '':
+        with open(args.log, 'a') as f:
+            f.write(f'{args.checkpoint}\t overlap: {args.overlap}\t seq_len: {args.seq_len}\t WER: {wer}\n')
+    print(f'wav2vec2 {args.mode}: {len(utterances)} utterances, {args.seconds:.0f} s of audio in {dt:.2f} s -> {args.seconds / dt:.1f} audio-s/s')
     return wer
 
 
-if __name__ == '__main__':
+def build_parser():
     ap = argparse.ArgumentParser()
-    ap.add_argument('-c', '--checkpoint', default='')
-    ap.add_argument('-seq', '--seq_len', type=int, default=131072)   # reference wav2vec2/lib.py:480-481 defaults
-    ap.add_argument('-o', '--overlap', type=int, default=0)
-    ap.add_argument('-epochs', '--epochs', type=int, default=1)
+    ap.add_argument('--mode', choices=['su', 'chunked'], default='su', help='su: tedlium/run.py (per utterance); chunked: earnings22/run.py')
     ap.add_argument('--seconds', type=float, default=900.0)
     ap.add_argument('--lr', type=float, default=1e-6)
     ap.add_argument('--seed', type=int, default=0)
-    main(ap.parse_args())
+    return ap
+
+
+if __name__ == '__main__':
+    main(lib.apply_args(build_parser()))

@@ -169,3 +169,20 @@ def dynamic_eval_ctc_loss(args, model, spec, seq_len, overlap, tokenizer, proces
 
 dynamic_eval = dynamic_eval_ctc_loss
 dynamic_eval_su = dynamic_eval_ctc_loss_su
+
+
+def apply_args(parser, argv=None):
+    """reference wav2vec2/lib.py:477-493 (same flags).  The reference falls back to `paths.checkpoints.wav2vec2` when -c is empty;
+    no paths.yaml / hub access exists offline, so an empty -c means seeded weights of the base-960h architecture."""
+    parser.add_argument('-c', '--checkpoint', type=str, default='', help='path to checkpoint')
+    parser.add_argument('-split', '--split', type=str, default='test', help='test or dev split')
+    parser.add_argument('-seq', '--seq_len', type=int, default=131072)
+    parser.add_argument('-overlap', '--overlap', type=int, default=0)
+    parser.add_argument('-nv', '--not_verbose', action='store_true', help='verbose')
+    parser.add_argument('-log', '--log', type=str, default='')
+    parser.add_argument('-shuffle', '--shuffle', action='store_true', help='shuffle')
+    parser.add_argument('-epochs', '--epochs', type=int, default=1, help='epochs')
+    parser.add_argument('-dfa', '--disable_flash_attention', action='store_true', help='disable flash attention')
+    args = parser.parse_args(argv)
+    args.verbose = not args.not_verbose
+    return args

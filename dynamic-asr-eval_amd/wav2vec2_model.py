@@ -161,6 +161,11 @@ class Wav2Vec2ForCTC:
         save = torch.is_grad_enabled()
         ctx = {"conv": []} if save else None
         B, L = x.shape
+        need = 1
+        for k, st in zip(reversed(c["conv_kernel"]), reversed(c["conv_stride"])):   # receptive field of the conv stack (400 samples)
+            need = (need - 1) * st + k
+        if L < need:
+            raise ops.DynError(f"input of {L} samples is shorter than the feature extractor's receptive field ({need} samples)")
         fe = "wav2vec2.feature_extractor.conv_layers."
         a = x.contiguous().view(B, L, 1)
         for i, (k, s) in enumerate(zip(c["conv_kernel"], c["conv_stride"])):

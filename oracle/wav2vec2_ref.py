@@ -1,4 +1,5 @@
-"""ORACLE (test infrastructure only).  CPU restatement of the reference's per-utterance wav2vec2 dynamic-eval loop
+"""ORACLE (test infrastructure only).  CPU restatements of the reference's wav2vec2 dynamic-eval loops: the chunked
+`dynamic_eval_ctc_loss` (reference wav2vec2/lib.py:41-235, see dynamic_eval_chunked_ref below) and the per-utterance loop
 `dynamic_eval_ctc_loss_su` (reference wav2vec2/lib.py:293-462) on the transformers CPU model (the class the reference
 itself loads, lib.py:20-23): snapshot weights (:314-315), CTCLoss(blank, reduction='mean') (:351), fresh optimiser (:354),
 per utterance: batch of num_negatives+1 identical waveforms (:385; the augmentation lines are commented out in the
@@ -45,3 +46,66 @@ def dynamic_eval_su_ref(args, model, utterances, tokenizer, optimizer_cls, num_n
     for p, po in zip(model.parameters(), original):
         p.data = po.data
     return utterances
+
+
+def dynamic_eval_chunked_ref(args, model, spec, seq_len, overlap, tokenizer, optimizer_cls, num_negatives=1, lr_args=None):
+    """reference wav2vec2/lib.py:41-235 on the transformers CPU model, statement by statement:
+    downsampling_factor hard-coded 4 (:59), snapshot (:63-64), CTCLoss(blank, reduction='sum') (:66), fresh optimiser (:98),
+    `seq_len > spec_n` rule (:104-105), overlap % 4 assert (:107), accumulators of spec_n // 4 + seq_len rows (:110), the inlined
+    window rule (:116-126), per epoch a fresh model_outputs (:133); per window: num_negatives + 2 copies (:141), feature-extractor
+    normalisation (:161), forward of all copies but the last (:163), log_softmax (:169), greedy pseudo-label of log_p[-1] (:170),
+    tokenise (:174), CTC of the first num_negatives copies / (N * B) (:177-181), zero_grad / backward / step (:193-197), keep
+    exp(log_p[-1]) with ds_len and overlap_ds = int(overlap / (u_len / ds_len)) (:205-210); stitch (:214-230); restore (:233-234).
+    NOT reproduced: the WavAugment effect chains applied to the first copies (:144-156; `augment` = facebookresearch/WavAugment is
+    un-vendored and absent) — the copies stay clean, as they do in the reference's own per-utterance variant (PARITY UNPINNED
+    for that augmentation)."""
+    from .dynamic_eval_ref import stitch_ref
+    spec_n = spec.shape[-1]
+    downsampling_factor = 4
+    original = [p.clone().detach() for p in model.parameters()]
+    ctc_loss_fn = torch.nn.CTCLoss(blank=tokenizer.blank_id, reduction='sum')
+    optimizer = optimizer_cls(model.parameters(), **(lr_args or {'lr': 1e-9}))
+    if seq_len > spec_n:
+        seq_len, overlap = spec_n, 0
+    assert overlap / downsampling_factor == overlap // downsampling_factor, 'Overlap must be a multiple of the downsampling factor'
+    V = tokenizer.vocab_size
+    all_logits, logit_count = torch.zeros((1, spec_n // 4 + seq_len, V)), torch.zeros((1, spec_n // 4 + seq_len, V))
+    last_ulen, kill_next = None, False
+    training_data = {}
+    for i in range(0, spec_n, seq_len - overlap):
+        audio_chunk = spec[:, i:i + seq_len]
+        u_len = audio_chunk.shape[-1]
+        if kill_next:
+            break
+        elif last_ulen is not None and u_len < last_ulen:
+            kill_next = True
+        last_ulen = u_len
+        training_data[i] = audio_chunk
+    model_outputs = {}
+    for epoch in range(args.__dict__.get('epochs', 1)):
+        model_outputs = {}
+        training_keys = list(training_data.keys())
+        training_keys = random.sample(training_keys, len(training_keys)) if args.__dict__.get('shuffle', False) else training_keys
+        for i in training_keys:
+            audio_chunk = training_data[i].clone()
+            audio_chunk = audio_chunk.repeat(num_negatives + 2, 1, 1).contiguous()
+            u_len = audio_chunk.shape[-1]
+            audio_chunk = audio_chunk.squeeze(1)
+            input_values = normalize_waveform(audio_chunk)
+            logits = model(input_values[:-1]).logits
+            log_p = F.log_softmax(logits, dim=-1)
+            pseudo = tokenizer.decode(greedy_ctc_ids(log_p[-1].detach(), tokenizer.blank_id))
+            targets = torch.LongTensor(tokenizer(pseudo).input_ids).unsqueeze(0).repeat(num_negatives, 1)
+            aug = log_p[:num_negatives]
+            N, B = aug.shape[1], aug.shape[0]
+            loss = ctc_loss_fn(aug.transpose(0, 1), targets, torch.LongTensor([N] * B), torch.LongTensor([targets.shape[1]] * B)) / (N * B)
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            probs = torch.exp(log_p[-1].detach())
+            ds_len = probs.shape[-2]
+            model_outputs[i] = {'logits': probs, 'ds_len': ds_len, 'overlap_ds': int(overlap / (u_len / ds_len))}
+    logits = stitch_ref(model_outputs, all_logits, logit_count)
+    for p, po in zip(model.parameters(), original):
+        p.data = po.data
+    return logits.squeeze(0).numpy()

@@ -80,3 +80,127 @@ def test_dynamic_eval_su_matches_oracle(cuda):
         assert a['probs'].shape == b['probs'].shape
         assert (a['probs'] - b['probs']).abs().max().item() < 1e-3
         assert torch.equal(a['probs'].argmax(-1), b['probs'].argmax(-1))
+
+
+# ------------------------------------------------------------------------------------------------ base-960h shape + chunked loop + harness
+def _base_pair(cuda, seed=0):
+    """The architecture the reference loads (wav2vec2/lib.py:20-23, facebook/wav2vec2-base-960h = transformers' Wav2Vec2Config()
+    defaults: 7 conv layers x 512 channels, positional conv k=128 g=16 with weight norm, 12 x 768, 12 heads, FFN 3072, vocab 32;
+    94.4 M parameters) with seeded weights (no hub access offline)."""
+    from transformers import Wav2Vec2Config, Wav2Vec2ForCTC as HF
+    from dynamic_asr_eval_amd.wav2vec2_model import Wav2Vec2ForCTC
+    torch.manual_seed(seed)
+    cfg = Wav2Vec2Config()
+    assert (cfg.hidden_size, cfg.num_hidden_layers, cfg.conv_dim[0], cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups,
+            cfg.vocab_size) == (768, 12, 512, 128, 16, 32)
+    ref = HF(cfg).eval()
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if p.dim() == 1 or "original0" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    hip = Wav2Vec2ForCTC(cfg, device=cuda)
+    hip.load_state_dict(ref.state_dict(), strict=False)
+    assert abs(sum(p.numel() for p in hip.parameters()) - sum(p.numel() for p in ref.parameters())) <= cfg.hidden_size   # masked_spec_embed
+    return ref, hip
+
+
+@pytest.fixture(scope="module")
+def base_pair(cuda):
+    return _base_pair(cuda)
+
+
+def test_base_960h_shape_forward_and_every_gradient(cuda, base_pair):
+    """Forward + every parameter gradient at the real architecture on 3 s and 2.3 s of audio (B = 2) vs the transformers CPU model."""
+    ref, hip = base_pair
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 48000, generator=g)
+    out_ref = ref(x).logits
+    out = hip(x.to(cuda)).logits
+    assert out.shape == out_ref.shape == (2, 149, 32)
+    err = (out.cpu() - out_ref).abs().max().item()
+    assert err < 5e-4, err
+    assert torch.equal(out.cpu().argmax(-1), out_ref.argmax(-1)) or (out_ref.topk(2, -1).values.diff(dim=-1).abs().min().item() < 1e-4)
+    gl = torch.randn(out_ref.shape, generator=g) / out_ref.numel()
+    ref.zero_grad()
+    out_ref.backward(gl)
+    hip.zero_grad(); hip.backward(gl.to(cuda))
+    grads = hip.grads_hf()
+    worst = 0.0
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            assert grads[n].abs().max().item() == 0.0, n
+            continue
+        diff = (grads[n].cpu().reshape(p.grad.shape) - p.grad).abs().max().item()
+        scale = p.grad.abs().max().item()
+        worst = max(worst, diff / (scale + 1e-12)) if scale > 1e-7 else worst
+        assert diff < 3e-3 * scale + 2e-8, (n, diff, scale)
+    print("base-960h: forward err", err, "worst relative gradient error", worst)
+
+
+@pytest.mark.parametrize("seq_len,overlap,epochs,L", [(6000, 0, 1, 15000), (6000, 1280, 1, 15000), (6000, 0, 2, 9000), (50000, 0, 1, 4000)])
+def test_chunked_dynamic_eval_matches_oracle(cuda, seq_len, overlap, epochs, L):
+    """Chunked loop (reference wav2vec2/lib.py:41-235): waveform windows by the inlined window rule, B = 2 clean copies, greedy
+    pseudo-label, CTC(sum) / (N * B), MADGRAD step, exp(log_p[-1]) stitched with overlap_ds = int(overlap / (u_len / ds_len));
+    several windows with a short tail, overlapping windows, 2 epochs (the last epoch's outputs are stitched), and a recording
+    shorter than seq_len."""
+    import argparse
+    import numpy as np
+    from oracle.wav2vec2_ref import dynamic_eval_chunked_ref
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import wav2vec2_lib as W
+    ref, hip = _pair(cuda, seed=7)
+    tok = W.CharTokenizer()
+    wav = torch.randn(1, L, generator=torch.Generator().manual_seed(L + overlap)) * 0.1 + 0.01
+    args = argparse.Namespace(epochs=epochs, shuffle=False)
+    before = hip.flat_params.clone()
+    want = dynamic_eval_chunked_ref(args, ref, wav, seq_len, overlap, tok, MADGRAD_REF, lr_args={'lr': 1e-5})
+    got = W.dynamic_eval(args, hip, wav, seq_len, overlap, tok, None, use_tqdm=False, optim=W.MADGRAD, lr_args={'lr': 1e-5})
+    assert torch.equal(hip.flat_params, before)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.abs(got - want).max() < 1e-3 and np.array_equal(got.argmax(-1), want.argmax(-1))
+
+
+def test_chunked_dynamic_eval_at_the_reference_window(cuda, base_pair):
+    """The reference's default window (`-seq 131072 -overlap 0`, wav2vec2/lib.py:480-481) at the base-960h architecture: a 9.4 s
+    recording = one full 131072-sample window ([2, 131072] -> logits [2, 409, 32]) + a short tail window."""
+    import argparse
+    import numpy as np
+    from oracle.wav2vec2_ref import dynamic_eval_chunked_ref
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import wav2vec2_lib as W
+    ref, hip = base_pair
+    tok = W.CharTokenizer()
+    wav = torch.randn(1, 150000, generator=torch.Generator().manual_seed(3)) * 0.1
+    args = argparse.Namespace(epochs=1, shuffle=False)
+    want = dynamic_eval_chunked_ref(args, ref, wav, 131072, 0, tok, MADGRAD_REF, lr_args={'lr': 1e-6})
+    got = W.dynamic_eval(args, hip, wav, 131072, 0, tok, None, use_tqdm=False, optim=W.MADGRAD, lr_args={'lr': 1e-6})
+    assert got.shape == want.shape == (409 + 58, 32)
+    err = np.abs(got - want).max()
+    bad = got.argmax(-1) != want.argmax(-1)
+    top2 = np.sort(want, -1)[:, -2:]
+    assert err < 1e-3 and not (bad & ((top2[:, 1] - top2[:, 0]) >= 5e-5)).any(), (err, int(bad.sum()))
+
+
+def test_run_wav2vec2_harness(cuda, tmp_path, capsys):
+    """run_wav2vec2.py: both reference drivers' flow (tedlium/run.py -> dynamic_eval_su, earnings22/run.py -> dynamic_eval), the
+    reference's flags, stdout lines and -log line; a local HF state_dict loads through -c and a foreign one is refused."""
+    from transformers import Wav2Vec2Config, Wav2Vec2ForCTC as HF
+    from dynamic_asr_eval_amd import run_wav2vec2 as R, wav2vec2_lib as W
+    log = str(tmp_path / "log.txt")
+    for mode in ("su", "chunked"):
+        args = W.apply_args(R.build_parser(), ["--mode", mode, "--seconds", "20", "-seq", "131072", "-overlap", "0", "-nv", "-log", log, "-epochs", "1"])
+        assert args.seq_len == 131072 and args.overlap == 0 and args.verbose is False and args.shuffle is False and args.split == "test"
+        wer = R.main(args)
+        out = capsys.readouterr().out
+        assert "Loaded model from" in out and "Total number of parameters: 94." in out and f"WER: {wer}" in out
+    lines = open(log).read().strip().split("\n")
+    assert len(lines) == 2 and all("\t overlap: 0\t seq_len: 131072\t WER: " in l for l in lines)
+    torch.manual_seed(0)
+    ck = str(tmp_path / "hf.pt")
+    torch.save(HF(Wav2Vec2Config()).state_dict(), ck)
+    args = W.apply_args(R.build_parser(), ["--mode", "su", "--seconds", "6", "-c", ck, "-nv"])
+    R.main(args)
+    assert f"Loaded model from {ck}" in capsys.readouterr().out
+    torch.save({"encoder.weight": torch.zeros(3)}, ck)
+    with pytest.raises(KeyError):
+        R.main(W.apply_args(R.build_parser(), ["--mode", "su", "--seconds", "6", "-c", ck, "-nv"]))
