@@ -29,6 +29,10 @@ class GemmDesc(ctypes.Structure):
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
         ("tile_m", ctypes.c_int32), ("tile_n", ctypes.c_int32), ("tail_slices", ctypes.c_int32), ("reserved_", ctypes.c_int32),
         ("C_in", ctypes.c_void_p),
+        ("epilogue", ctypes.c_int32), ("reserved2_", ctypes.c_int32),
+        ("aux", ctypes.c_void_p),
+        ("a_colsum", ctypes.c_void_p),
+        ("a_colsum_beta", ctypes.c_float), ("reserved3_", ctypes.c_float),
     ]
 
 

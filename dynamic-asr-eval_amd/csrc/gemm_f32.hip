@@ -58,7 +58,21 @@ struct KParams {
     int64_t full_items;  // work items (batch, tile, k-split) handled by one workgroup each; the rest is the TAIL
     int tail_f;          // every tail item is cut into tail_f K-slices so the last partial round of workgroups still
     float* tail_ws;      // fills the chip; slices go to tile-local slabs [tail item][slice][BM][BN] and are summed in order
+    // epilogue extras (interior, non-split path only)
+    int epi;             // DYN_GEMM_EPI_*: 0 none; 1 C = silu(v), aux = v (pre-activation kept for the backward); 2 C = v * silu'(aux)
+    float* aux;          // addressed like C (same ldc / batch strides)
+    // grouped launches only
+    float* colsum;       // [M]: colsum[m] = colsum_beta * colsum[m] + sum_k A(m, k)   (bias gradient of a weight-gradient GEMM)
+    float colsum_beta;
+    int64_t first_item;  // first work item of this group in the grouped launch
 };
+
+// same formulas as silu_fwd_kernel / silu_bwd_kernel (elementwise.hip): fused and unfused paths agree bit for bit
+__device__ __forceinline__ float silu_f(float v) { return v * dyn::sigmoidf_(v); }
+__device__ __forceinline__ float silu_grad_f(float u) {
+    const float sg = dyn::sigmoidf_(u);
+    return sg * (1.f + u * (1.f - sg));
+}
 
 // Stage one operand tile (R rows x BK) from HBM into registers.
 // Interior tiles (every row and the whole K step in bounds, 16-B aligned): branch-free 16-B loads that the compiler
@@ -218,22 +232,24 @@ __device__ __forceinline__ void read_frag_glds(const float* __restrict__ s, int 
     }
 }
 
-template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS>
-__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
+// One output tile (or one K slice of it) by one 256-thread workgroup.  `bid` = position of this workgroup among the launch's work
+// items (the single-GEMM kernel passes blockIdx.x; the grouped kernel passes the index inside the group, already remapped).
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, bool GROUPED>
+__device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, float* smem) {
     constexpr bool AK = !TA;  // A has K contiguous in HBM
     constexpr bool BKM = TB;  // B has K contiguous in HBM
     constexpr int WTM = BM / 64, WTN = BN / 64;  // 32x32 tiles per wave along M / N
     static_assert(!GLDS || (VEC && BK == 32), "direct-to-LDS staging needs 16-B aligned operands and BK = 32");
     constexpr int SA = GLDS ? BM * BK : BM * LDK, SB = GLDS ? BN * BK : BN * LDK;  // floats per stage
-    __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
 
     // Work item of this workgroup.  Full items: XCD-aware bijective remap (blocks with equal blockIdx.x % 8 share an
     // XCD/L2, so each XCD walks a contiguous run of tiles).  Tail items come last in dispatch order and are K-sliced.
-    const int64_t bid = blockIdx.x;
-    const bool is_tail = bid >= p.full_items;
+    const bool is_tail = !GROUPED && bid >= p.full_items;
     int64_t item;
     int sub = 0;
-    if (!is_tail) {
+    if (GROUPED) {
+        item = bid;          // the grouped kernel remaps over the whole launch before it picks the group
+    } else if (!is_tail) {
         const int64_t nwg = p.full_items;
         const int64_t xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -326,7 +342,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
             else read_frag<BKM, BN>(sb, wn * (BN / 2) + b * 32, i, h, c, fb[slot][b]);
         }
     };
+    // grouped weight-gradient launches: the first column of tiles also sums its A panel over K (the bias gradient), from the
+    // fragments that are in registers anyway; waves wn == 0 only (both wn read the same A fragments)
+    float csum[WTM];
+#pragma unroll
+    for (int a = 0; a < WTM; ++a) csum[a] = 0.f;
+    const bool do_colsum = GROUPED && p.colsum != nullptr && tn == 0 && wn == 0;
     auto mfma_chunk = [&](int slot) {
+        if (GROUPED && do_colsum) {
+#pragma unroll
+            for (int a = 0; a < WTM; ++a) csum[a] += (fa[slot][a][0] + fa[slot][a][1]) + (fa[slot][a][2] + fa[slot][a][3]);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -370,6 +396,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
         cur ^= 1;
     }
 
+    if (GROUPED && do_colsum) {   // lane halves hold the two k sub-ranges of every chunk: fold them, then lanes h == 0 own row i
+#pragma unroll
+        for (int a = 0; a < WTM; ++a) {
+            const float tot = csum[a] + __shfl_xor(csum[a], 32);
+            const int64_t m = m0 + wm * (BM / 2) + a * 32 + i;
+            if (h == 0 && m < p.M) p.colsum[m] = (p.colsum_beta != 0.f ? p.colsum_beta * p.colsum[m] : 0.f) + tot;
+        }
+    }
     // Epilogue. C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     if (is_tail) {
         float* W = p.tail_ws + ((item - p.full_items) * p.tail_f + sub) * (int64_t)(BM * BN);
@@ -403,7 +437,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
                 const int64_t col = n0 + wn * (BN / 2) + b * 32 + i;
                 const float bv = p.bias ? p.bias[col] : 0.f;
                 float* cp = C + (m0 + wm * (BM / 2) + a * 32 + 4 * h) * p.ldc + col;
-                if (p.beta != 0.f) {
+                if (p.epi != 0) {             // activation fused into the store (host guarantees: no split / tail, aux set)
+                    const int64_t ad = p.aux - p.C;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float* q2 = cp + (int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc;
+                        float v = p.alpha * acc[a][b][e] + bv;
+                        if (p.beta != 0.f) v += p.beta * q2[p.cin_delta];
+                        if (p.epi == 1) { if (p.aux) q2[ad] = v; *q2 = silu_f(v); }
+                        else *q2 = v * silu_grad_f(q2[ad]);
+                    }
+                } else if (p.beta != 0.f) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         float* q2 = cp + (int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc;
@@ -426,13 +470,53 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
                 for (int e = 0; e < 16; ++e) {
                     const int64_t row = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (row < p.M && col < p.N) {
-                        float v = p.alpha * acc[a][b][e];
+                        float v = p.alpha * acc[a][b][e] + bv;
                         if (p.beta != 0.f) v += p.beta * C[row * p.ldc + col + p.cin_delta];
-                        C[row * p.ldc + col] = v + bv;
+                        if (p.epi == 1) { if (p.aux) C[row * p.ldc + col + (p.aux - p.C)] = v; v = silu_f(v); }
+                        else if (p.epi == 2) v *= silu_grad_f(C[row * p.ldc + col + (p.aux - p.C)]);
+                        C[row * p.ldc + col] = v;
                     }
                 }
             }
     }
+}
+
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
+    constexpr int SA = GLDS ? BM * BK : BM * LDK, SB = GLDS ? BN * BK : BN * LDK;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
+    gemm_tile<TA, TB, BM, BN, VEC, GLDS, false>(p, (int64_t)blockIdx.x, smem);
+}
+
+// Grouped launch: ONE grid over the tiles of up to kMaxGroups independent GEMMs that share (TA, TB) and the tile shape (the
+// deferred weight-gradient products of a whole backward pass: each alone has 36-144 tiles of 128x128, far too few for 256 CUs).
+// The descriptor table lives in device memory (written by gemm_table_kernel from kernel arguments, so the pair is capturable in
+// a hipGraph); a workgroup remaps its index XCD-wise over the whole launch, finds its group by binary search over first_item
+// and runs the ordinary tile body.  No split-K and no tail slicing: the launch has thousands of tiles.
+constexpr int kMaxGroups = 96;
+constexpr int kTableChunk = 12;
+struct KTableChunk { KParams g[kTableChunk]; };
+
+__global__ void gemm_table_kernel(const KTableChunk chunk, KParams* __restrict__ table, int base, int count) {
+    const int t = threadIdx.x;
+    if (t < count) table[base + t] = chunk.g[t];
+}
+
+template <bool TA, bool TB, int BM, int BN, bool GLDS>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_grouped_kernel(const KParams* __restrict__ table, int n_groups, int64_t total_items) {
+    constexpr int SA = GLDS ? BM * BK : BM * LDK, SB = GLDS ? BN * BK : BN * LDK;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
+    const int64_t bid = blockIdx.x;
+    const int64_t xcd = bid & 7, q = total_items >> 3, r = total_items & 7;
+    const int64_t item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int lo = 0, hi = n_groups - 1;            // last group whose first_item <= item
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_item <= item) lo = mid; else hi = mid - 1;
+    }
+    const int g = __builtin_amdgcn_readfirstlane(lo);
+    const KParams p = table[g];
+    gemm_tile<TA, TB, BM, BN, true, GLDS, true>(p, item - p.first_item, smem);
 }
 
 __global__ void splitk_reduce_kernel(const KParams p) {
@@ -449,6 +533,8 @@ __global__ void splitk_reduce_kernel(const KParams p) {
         float v = p.alpha * s;
         if (p.beta != 0.f) v += p.beta * C[p.cin_delta];
         if (p.bias) v += p.bias[col];
+        if (p.epi == 1) { if (p.aux) C[p.aux - p.C] = v; v = silu_f(v); }
+        else if (p.epi == 2) v *= silu_grad_f(C[p.aux - p.C]);
         *C = v;
     }
 }
@@ -483,6 +569,8 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(const KParams p, int B
                 float o = p.alpha * v[j];
                 if (p.beta != 0.f) o += p.beta * C[col + p.cin_delta];
                 if (p.bias) o += p.bias[col];
+                if (p.epi == 1) { if (p.aux) C[col + (p.aux - p.C)] = o; o = silu_f(o); }
+                else if (p.epi == 2) o *= silu_grad_f(C[col + (p.aux - p.C)]);
                 C[col] = o;
             }
         }
@@ -616,6 +704,9 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
                 (long long)d->K, (long long)d->nb1, (long long)d->nb2);
     if (d->M == 0 || d->N == 0) return DYN_OK;
     DYN_REQUIRE(d->A && d->B && d->C, DYN_E_ARG, "dyn_gemm_f32: null operand");
+    DYN_REQUIRE(d->epilogue >= 0 && d->epilogue <= 2 && (d->epilogue != 2 || d->aux), DYN_E_ARG,
+                "dyn_gemm_f32: epilogue %d needs 0 <= mode <= 2 (and aux for mode 2)", d->epilogue);
+    DYN_REQUIRE(d->a_colsum == nullptr, DYN_E_ARG, "dyn_gemm_f32: a_colsum is a grouped-launch feature (dyn_gemm_f32_grouped)");
     // lda < K is allowed for a non-transposed A: overlapping rows = frames of a 1-D signal (the STFT as an implicit GEMM)
     DYN_REQUIRE(d->lda >= (d->trans_a ? d->M : 1) && d->ldb >= (d->trans_b ? d->K : 1) && d->ldc >= d->N,
                 DYN_E_ARG, "dyn_gemm_f32: leading dimension smaller than the row length");
@@ -651,6 +742,8 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
     kp.full_items = pl.full_items;
     kp.tail_f = pl.tail_f;
     kp.tail_ws = (float*)d->workspace;
+    kp.epi = d->epilogue; kp.aux = d->aux;
+    kp.colsum = nullptr; kp.colsum_beta = 0.f; kp.first_item = 0;
     const int64_t nblocks = pl.full_items + pl.tail_items * pl.tail_f;
     DYN_REQUIRE(nblocks < (1ll << 31) && tiles_m * tiles_n < (1ll << 31), DYN_E_ARG, "dyn_gemm_f32: grid too large (%lld workgroups)",
                 (long long)nblocks);
@@ -678,4 +771,80 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
         rc = dyn::check_launch("dyn_gemm_f32(tail_reduce)");
     }
     return rc;
+}
+
+extern "C" int64_t dyn_gemm_f32_grouped_workspace_bytes(int32_t n) {
+    return (int64_t)(n > 0 ? n : 0) * (int64_t)sizeof(KParams);
+}
+
+extern "C" int dyn_gemm_f32_grouped(const dyn_gemm_desc* descs, int32_t n, void* workspace, int64_t workspace_bytes, void* stream) {
+    DYN_REQUIRE(descs != nullptr && n >= 0 && n <= kMaxGroups, DYN_E_ARG, "dyn_gemm_f32_grouped: need 0 <= n <= %d descriptors", kMaxGroups);
+    if (n == 0) return DYN_OK;
+    DYN_REQUIRE(workspace && workspace_bytes >= dyn_gemm_f32_grouped_workspace_bytes(n), DYN_E_WORKSPACE,
+                "dyn_gemm_f32_grouped: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                (long long)dyn_gemm_f32_grouped_workspace_bytes(n));
+    const bool ta = descs[0].trans_a != 0, tb = descs[0].trans_b != 0;
+    constexpr int BM = 128, BN = 128;
+    auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+    bool glds = true;
+    KParams host[kMaxGroups];
+    int64_t total = 0;
+    int used = 0;
+    for (int g = 0; g < n; ++g) {
+        const dyn_gemm_desc* d = &descs[g];
+        DYN_REQUIRE((d->trans_a != 0) == ta && (d->trans_b != 0) == tb, DYN_E_ARG, "dyn_gemm_f32_grouped: group %d has other transpose flags", g);
+        DYN_REQUIRE(d->nb1 == 1 && d->nb2 == 1 && d->split_k == 0 && d->epilogue == 0 && d->bias == nullptr, DYN_E_ARG,
+                    "dyn_gemm_f32_grouped: group %d: batches, split-K, bias and activation epilogues are not supported here", g);
+        DYN_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, DYN_E_ARG, "dyn_gemm_f32_grouped: group %d has a negative size", g);
+        if (d->M == 0 || d->N == 0) continue;
+        DYN_REQUIRE(d->A && d->B && d->C, DYN_E_ARG, "dyn_gemm_f32_grouped: group %d has a null operand", g);
+        DYN_REQUIRE(d->lda >= (ta ? d->M : d->K) && d->ldb >= (tb ? d->K : d->N) && d->ldc >= d->N, DYN_E_ARG,
+                    "dyn_gemm_f32_grouped: group %d: leading dimension smaller than the row length", g);
+        DYN_REQUIRE(al16(d->A) && al16(d->B) && d->lda % 4 == 0 && d->ldb % 4 == 0, DYN_E_ARG,
+                    "dyn_gemm_f32_grouped: group %d: operands must be 16-byte aligned with leading dimensions that are multiples of 4", g);
+        DYN_REQUIRE(d->a_colsum == nullptr || ta, DYN_E_ARG, "dyn_gemm_f32_grouped: a_colsum needs trans_a (A stored [K][M])");
+        glds = glds && d->K % BK == 0 && d->K > 0 && (!ta || (d->M % 4 == 0 && d->M >= 4)) && (tb || (d->N % 4 == 0 && d->N >= 4));
+        KParams& kp = host[used++];
+        kp.M = d->M; kp.N = d->N; kp.K = d->K;
+        kp.A = d->A; kp.lda = d->lda; kp.sa1 = 0; kp.sa2 = 0;
+        kp.B = d->B; kp.ldb = d->ldb; kp.sb1 = 0; kp.sb2 = 0;
+        kp.C = d->C; kp.ldc = d->ldc; kp.sc1 = 0; kp.sc2 = 0;
+        kp.cin_delta = d->C_in ? (int64_t)(d->C_in - d->C) : 0;
+        kp.bias = nullptr; kp.alpha = d->alpha; kp.beta = d->beta;
+        kp.nb2 = 1; kp.splits = 1; kp.kchunk = dyn::cdiv(d->K > 0 ? d->K : 1, BK) * BK;
+        kp.ws = nullptr; kp.nbatch = 1;
+        kp.tiles_m = (int)dyn::cdiv(d->M, BM); kp.tiles_n = (int)dyn::cdiv(d->N, BN);
+        kp.n_major = 0;       // row-major runs of tiles: consecutive tiles share the A panel (dy), the operand the bias sums also read
+        kp.tiles_per_batch = (int64_t)kp.tiles_m * kp.tiles_n;
+        kp.full_items = kp.tiles_per_batch; kp.tail_f = 1; kp.tail_ws = nullptr;
+        kp.epi = 0; kp.aux = nullptr;
+        kp.colsum = d->a_colsum; kp.colsum_beta = d->a_colsum_beta;
+        kp.first_item = total;
+        total += kp.tiles_per_batch;
+    }
+    if (used == 0) return DYN_OK;
+    DYN_REQUIRE(total < (1ll << 31), DYN_E_ARG, "dyn_gemm_f32_grouped: grid too large");
+    static const bool allow_glds = [] { const char* e = getenv("DYN_GEMM_GLDS"); return !e || atoi(e) != 0; }();
+    glds = glds && allow_glds;
+    hipStream_t st = (hipStream_t)stream;
+    KParams* table = (KParams*)workspace;
+    for (int base = 0; base < used; base += kTableChunk) {
+        KTableChunk chunk;
+        const int cnt = used - base < kTableChunk ? used - base : kTableChunk;
+        for (int t = 0; t < cnt; ++t) chunk.g[t] = host[base + t];
+        for (int t = cnt; t < kTableChunk; ++t) chunk.g[t] = host[base];
+        hipLaunchKernelGGL(gemm_table_kernel, dim3(1), dim3(64), 0, st, chunk, table, base, cnt);
+    }
+    dim3 grid((unsigned)total);
+#define GO_G(TA_, TB_)                                                                                                              \
+    do {                                                                                                                            \
+        if (glds) hipLaunchKernelGGL((gemm_f32_grouped_kernel<TA_, TB_, BM, BN, true>), grid, dim3(NTHREADS), 0, st, table, used, total); \
+        else hipLaunchKernelGGL((gemm_f32_grouped_kernel<TA_, TB_, BM, BN, false>), grid, dim3(NTHREADS), 0, st, table, used, total);     \
+    } while (0)
+    if (ta && !tb) GO_G(true, false);
+    else if (!ta && tb) GO_G(false, true);
+    else if (!ta && !tb) GO_G(false, false);
+    else GO_G(true, true);
+#undef GO_G
+    return dyn::check_launch("dyn_gemm_f32_grouped");
 }

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
                                                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                         const float* __restrict__ dy, float* dx, float dx_beta,
                                                         float* __restrict__ partial_g, float* __restrict__ partial_b,
-                                                        int64_t rows) {
+                                                        int64_t rows, const float* dx_in) {
     constexpr int C = NV * 256;
     __shared__ float4 red[WPB][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
             o.w = rstd * (gy[j].w - s1 - xh[j].w * s2);
             float4* p = reinterpret_cast<float4*>(dx + row * C) + lane + 64 * j;
             if (dx_beta != 0.f) {
-                const float4 old = *p;
+                const float4 old = reinterpret_cast<const float4*>(dx_in + row * C)[lane + 64 * j];   // dx_in == dx: in place
                 o.x += dx_beta * old.x; o.y += dx_beta * old.y; o.z += dx_beta * old.z; o.w += dx_beta * old.w;
             }
             *p = o;
@@ -161,18 +161,19 @@ int launch_fwd(const float* x, const float* gamma, const float* beta, float* y, 
 template <bool RMS>
 int launch_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
                float dx_beta, float* dgamma, float* dbeta, float wbeta, int64_t rows, int64_t C, void* ws, int64_t ws_bytes,
-               hipStream_t st) {
+               hipStream_t st, const float* dx_in = nullptr) {
+    if (dx_in == nullptr) dx_in = dx;
     const int nb = bwd_blocks(rows);
     DYN_REQUIRE(ws && ws_bytes >= (int64_t)2 * nb * C * (int64_t)sizeof(float), DYN_E_WORKSPACE, "norm_bwd: workspace too small");
     float* pg = (float*)ws;
     float* pb = pg + (int64_t)nb * C;
     dim3 grid(nb), blk(256);
     switch (C / 256) {
-        case 1: hipLaunchKernelGGL((norm_bwd_kernel<1, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows); break;
-        case 2: hipLaunchKernelGGL((norm_bwd_kernel<2, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows); break;
-        case 3: hipLaunchKernelGGL((norm_bwd_kernel<3, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows); break;
-        case 4: hipLaunchKernelGGL((norm_bwd_kernel<4, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows); break;
-        case 8: hipLaunchKernelGGL((norm_bwd_kernel<8, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows); break;
+        case 1: hipLaunchKernelGGL((norm_bwd_kernel<1, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in); break;
+        case 2: hipLaunchKernelGGL((norm_bwd_kernel<2, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in); break;
+        case 3: hipLaunchKernelGGL((norm_bwd_kernel<3, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in); break;
+        case 4: hipLaunchKernelGGL((norm_bwd_kernel<4, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in); break;
+        case 8: hipLaunchKernelGGL((norm_bwd_kernel<8, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in); break;
         default: dyn::set_error("norm: unsupported C=%lld", (long long)C); return DYN_E_UNSUPPORTED;
     }
     if (!RMS && dgamma && dbeta) dyn::launch_reduce_partials_pair(pg, dgamma, pb, dbeta, (int64_t)nb, C, wbeta, st);
@@ -274,6 +275,16 @@ extern "C" int dyn_layernorm_bwd(const float* x, const float* gamma, const float
     if (rows == 0) return DYN_OK;
     return launch_bwd<false>(x, gamma, mean, rstd, dy, dx, dx_beta, dgamma, dbeta, wgrad_beta, rows, C, workspace,
                              workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int dyn_layernorm_bwd_res(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy,
+                                     const float* dx_in, float* dx, float dx_beta, float* dgamma, float* dbeta, float wgrad_beta,
+                                     int64_t rows, int64_t C, void* workspace, int64_t workspace_bytes, void* stream) {
+    DYN_REQUIRE(x && gamma && mean && rstd && dy && dx && dx_in && rows >= 0 && C > 0 && C % 256 == 0, DYN_E_ARG,
+                "dyn_layernorm_bwd_res: bad arguments");
+    if (rows == 0) return DYN_OK;
+    return launch_bwd<false>(x, gamma, mean, rstd, dy, dx, dx_beta, dgamma, dbeta, wgrad_beta, rows, C, workspace,
+                             workspace_bytes, (hipStream_t)stream, dx_in);
 }
 
 extern "C" int dyn_rmsnorm_fwd(const float* x, const float* gamma, float* y, float* rstd, int64_t rows, int64_t C, float eps,

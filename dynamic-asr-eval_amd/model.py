@@ -144,6 +144,9 @@ class SCConformerXL:
         self._ctx_static = False
         self._ctx_key = None
         self.fused_convmod = True   # GLU + dwconv + norm + SiLU in one kernel (csrc/convmod.hip)
+        self.fused_silu = True      # SiLU / SiLU' inside the epilogue of the GEMM that produces its argument (dyn_gemm_desc.epilogue)
+        self.grouped_wgrad = True   # block weight gradients deferred to ONE grouped launch at the end of the backward (+ bias sums)
+        self._wq = None
         self.training = False
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -207,13 +210,35 @@ class SCConformerXL:
             self._rot[T] = (ang.cos().float().to(self.device).contiguous(), ang.sin().float().to(self.device).contiguous())
         return self._rot[T]
 
-    def _lin_bwd(self, dy, x, wname, bname=None, need_dx=True, alpha=1.0):
-        """Accumulates dW (and db) for y = x @ W^T + b and returns alpha * dy @ W (or None)."""
-        if self.trainable(wname) and not self._skip_wgrad:
+    def _lin_bwd(self, dy, x, wname, bname=None, need_dx=True, alpha=1.0, silu_of=None):
+        """Accumulates dW (and db) for y = x @ W^T + b and returns alpha * dy @ W (or None); with `silu_of` = u the returned
+        gradient is multiplied by silu'(u) (the activation that produced x) in the GEMM's epilogue.
+        While a deferred-wgrad queue is open (`_backward`), the weight gradient of a block-local weight is only QUEUED: dy and x
+        must then stay unmodified until the queue is flushed (the residual-stream gradient gets a new buffer per module)."""
+        wg = self.trainable(wname) and not self._skip_wgrad
+        bg = bname is not None and self.trainable(bname) and not self._skip_wgrad   # bitfit trains a bias under a frozen weight
+        if wg and self._wq is not None and (wname.startswith("layers.") or wname == "subsampling.out.weight"):
+            self._wq.append(ops.wgrad_desc(dy, x, self.G[wname], alpha=alpha, beta=1.0, colsum=self.G[bname] if bg else None, colsum_beta=1.0))
+            bg = False
+        elif wg:
             ops.linear_wgrad(dy, x, self.G[wname], alpha=alpha, beta=1.0)
-        if bname is not None and self.trainable(bname) and not self._skip_wgrad:    # bitfit trains a bias under a frozen weight
+        if bg:
             ops.colsum(dy, self.G[bname], beta=1.0)
-        return ops.linear_dgrad(dy, self.P[wname], alpha=alpha) if need_dx else None
+        if not need_dx:
+            return None
+        if silu_of is not None and self.fused_silu:
+            return ops.linear_dgrad(dy, self.P[wname], alpha=alpha, epilogue=ops.EPI_SILU_GRAD, aux=silu_of)
+        dx = ops.linear_dgrad(dy, self.P[wname], alpha=alpha)
+        return ops.silu_bwd(silu_of, dx, out=dx) if silu_of is not None else dx
+
+    def _res_norm_bwd(self, h, wn, bn_, mean, rstd, dn, dh):
+        """dh_out = dh + LayerNorm_bwd(dn): in place, or into a NEW buffer while weight gradients that read dh are still queued."""
+        if self._wq is None:
+            ops.layernorm_bwd(h, self.P[wn], mean, rstd, dn, dh, self.G[wn], self.G[bn_], dx_beta=1.0)
+            return dh
+        out = torch.empty_like(dh)
+        ops.layernorm_bwd(h, self.P[wn], mean, rstd, dn, out, self.G[wn], self.G[bn_], dx_beta=1.0, dx_in=dh)
+        return out
 
     # ------------------------------------------------------------------ forward
     def __call__(self, audio_signal=None, **kw):
@@ -241,7 +266,7 @@ class SCConformerXL:
             self._ctx_static = False
             return self._forward_eager(x)
         G = self._graphs
-        key = (tuple(x.shape), torch.is_grad_enabled(), self.fused_convmod, self.fused_attention)
+        key = (tuple(x.shape), torch.is_grad_enabled(), self.fused_convmod, self.fused_attention, self.fused_silu)
         ent = G["fwd"].get(key)
         if ent is None:
             G["seen"][key] = G["seen"].get(key, 0) + 1
@@ -284,8 +309,12 @@ class SCConformerXL:
         u2 = ops.dwconv2d_s2(z1, P["subsampling.dw2.weight"], P["subsampling.dw2.bias"])
         z2 = ops.linear(u2, P["subsampling.pw2.weight"], P["subsampling.pw2.bias"])
         u3 = ops.dwconv2d_s2(z2, P["subsampling.dw3.weight"], P["subsampling.dw3.bias"])
-        z3 = ops.linear(u3, P["subsampling.pw3.weight"], P["subsampling.pw3.bias"])
-        a3 = ops.silu(z3)
+        if self.fused_silu:
+            z3 = torch.empty(*u3.shape[:-1], C, device=x.device, dtype=torch.float32) if save else None
+            a3 = ops.linear(u3, P["subsampling.pw3.weight"], P["subsampling.pw3.bias"], epilogue=ops.EPI_SILU, aux=z3)
+        else:
+            z3 = ops.linear(u3, P["subsampling.pw3.weight"], P["subsampling.pw3.bias"])
+            a3 = ops.silu(z3)
         T3, F3 = a3.shape[1], a3.shape[2]
         h = ops.linear(a3.view(B, T3, F3 * C), P["subsampling.out.weight"], P["subsampling.out.bias"])
         if save:
@@ -328,8 +357,12 @@ class SCConformerXL:
     def _ff_fwd(self, h, p, lc, key):
         P, eps = self.P, self.config["norm_eps"]
         n, mean, rstd = ops.layernorm(h, P[p + ".norm.weight"], P[p + ".norm.bias"], eps)
-        u = ops.linear(n, P[p + ".w1.weight"])
-        a = ops.silu(u)
+        if self.fused_silu:
+            u = torch.empty(*n.shape[:-1], P[p + ".w1.weight"].shape[0], device=n.device, dtype=torch.float32) if lc is not None else None
+            a = ops.linear(n, P[p + ".w1.weight"], epilogue=ops.EPI_SILU, aux=u)
+        else:
+            u = ops.linear(n, P[p + ".w1.weight"])
+            a = ops.silu(u)
         if lc is not None:   # keep h for the backward: the GEMM reads the residual from h and writes a new buffer
             out = ops.linear(a, P[p + ".w2.weight"], alpha=0.5, beta=1.0, residual=h)
         else:
@@ -419,10 +452,11 @@ class SCConformerXL:
                 return self._backward(grad_posteriors, n_active, input_grad)
         finally:
             self._skip_wgrad = False
+            self._wq = None
 
     def _backward_graphed(self, grad_posteriors, n_active):
         G = self._graphs
-        key = (self._ctx_key, tuple(grad_posteriors.shape), n_active, frozenset(self.frozen))
+        key = (self._ctx_key, tuple(grad_posteriors.shape), n_active, frozenset(self.frozen), self.grouped_wgrad, self.fused_silu)
         ent = G["bwd"].get(key)
         if ent is None:
             static_g = grad_posteriors.contiguous().clone()
@@ -466,6 +500,7 @@ class SCConformerXL:
             ctx["sub"] = cut(ctx["sub"])
             ctx["dims"] = (nb, T, T3, F3)
         h, mean, rstd, n, logp = ctx["head"]
+        self._wq = [] if (self.grouped_wgrad and not self._skip_wgrad) else None
         dz = ops.log_softmax_bwd(logp, grad_posteriors.contiguous())
         dn = self._lin_bwd(dz, n, "decoder.ff.weight", "decoder.ff.bias")
         dh = torch.empty_like(h)
@@ -487,12 +522,15 @@ class SCConformerXL:
             ops.layernorm_bwd(h0, P[p + "norm_out.weight"], mean, rstd, dh, dh2, G[p + "norm_out.weight"],
                               G[p + "norm_out.bias"], dx_beta=0.0)
             dh = dh2
-            self._ff_bwd(dh, p + "ff2", lc["ff2"])
-            self._conv_bwd(dh, p + "conv", lc["conv"])
-            self._attn_bwd(dh, p + "attn", lc["attn"])
-            self._ff_bwd(dh, p + "ff1", lc["ff1"])
-            ctx["layers"][l] = None  # release this block's activations
+            dh = self._ff_bwd(dh, p + "ff2", lc["ff2"])
+            dh = self._conv_bwd(dh, p + "conv", lc["conv"])
+            dh = self._attn_bwd(dh, p + "attn", lc["attn"])
+            dh = self._ff_bwd(dh, p + "ff1", lc["ff1"])
+            ctx["layers"][l] = None  # release this block's activations (queued weight gradients keep what they read)
         dx = self._sub_bwd(dh, ctx, input_grad)
+        if self._wq:
+            ops.gemm_grouped(self._wq)      # every block weight gradient (+ bias sums) of this backward: one launch
+        self._wq = None
         if not static:
             self._ctx = None
         for name, _ in self.spec:
@@ -503,10 +541,9 @@ class SCConformerXL:
     def _ff_bwd(self, dh, p, saved):
         h, mean, rstd, n, u, a = saved
         P, G = self.P, self.G
-        da = self._lin_bwd(dh, a, p + ".w2.weight", None, alpha=0.5)
-        du = ops.silu_bwd(u, da, out=da)
+        du = self._lin_bwd(dh, a, p + ".w2.weight", None, alpha=0.5, silu_of=u)
         dn = self._lin_bwd(du, n, p + ".w1.weight", None)
-        ops.layernorm_bwd(h, P[p + ".norm.weight"], mean, rstd, dn, dh, G[p + ".norm.weight"], G[p + ".norm.bias"], dx_beta=1.0)
+        return self._res_norm_bwd(h, p + ".norm.weight", p + ".norm.bias", mean, rstd, dn, dh)
 
     def _attn_bwd(self, dh, p, saved):
         cfg, P, G = self.config, self.P, self.G
@@ -534,13 +571,12 @@ class SCConformerXL:
         cos, sin = self._rotary(T)
         ops.rotary(dqkv, cos, sin, B, T, 2 * H, D, 3 * HD, inverse=True)
         dn = self._lin_bwd(dqkv, n, p + ".qkv.weight", p + ".qkv.bias")
-        ops.layernorm_bwd(h, P[p + ".norm.weight"], mean, rstd, dn, dh, G[p + ".norm.weight"], G[p + ".norm.bias"], dx_beta=1.0)
+        return self._res_norm_bwd(h, p + ".norm.weight", p + ".norm.bias", mean, rstd, dn, dh)
 
     def _conv_bwd(self, dh, p, saved):
         cfg, P, G = self.config, self.P, self.G
         h, mean, rstd, n, u, g, c, stats, nn_, s = saved
-        ds = self._lin_bwd(dh, s, p + ".pw2.weight", p + ".pw2.bias")
-        dnn = ops.silu_bwd(nn_, ds, out=ds)
+        dnn = self._lin_bwd(dh, s, p + ".pw2.weight", p + ".pw2.bias", silu_of=nn_)
         dc = torch.empty_like(c)
         if cfg["conv_norm"] == "rms_norm":
             ops.rmsnorm_bwd(c, P[p + ".cnorm.weight"], stats[1], dnn, dc, G[p + ".cnorm.weight"], dx_beta=0.0)
@@ -555,7 +591,7 @@ class SCConformerXL:
         dg = ops.dwconv1d_dgrad(dc, P[p + ".dw.weight"])
         du = ops.glu_bwd(u, dg)
         dn = self._lin_bwd(du, n, p + ".pw1.weight", p + ".pw1.bias")
-        ops.layernorm_bwd(h, P[p + ".norm.weight"], mean, rstd, dn, dh, G[p + ".norm.weight"], G[p + ".norm.bias"], dx_beta=1.0)
+        return self._res_norm_bwd(h, p + ".norm.weight", p + ".norm.bias", mean, rstd, dn, dh)
 
     def _sub_bwd(self, dh, ctx, input_grad=False):
         if not self.trainable("subsampling.") and not input_grad:
@@ -565,8 +601,8 @@ class SCConformerXL:
         xt, z1, u2, z2, u3, z3, a3 = ctx["sub"]
         B, T, T3, F3 = ctx["dims"]
         C = self.config["subsampling_conv_channels"]
-        da3 = self._lin_bwd(dh, a3.view(B, T3, F3 * C), "subsampling.out.weight", "subsampling.out.bias")
-        dz3 = ops.silu_bwd(z3, da3.view_as(z3), out=da3.view_as(z3))
+        dz3 = self._lin_bwd(dh, a3.view(B, T3, F3 * C), "subsampling.out.weight", "subsampling.out.bias",
+                            silu_of=z3.view(B, T3, F3 * C)).view_as(z3)
         du3 = self._lin_bwd(dz3, u3, "subsampling.pw3.weight", "subsampling.pw3.bias")
         if wg:
             ops.dwconv2d_s2_wgrad(z2, du3, G["subsampling.dw3.weight"], G["subsampling.dw3.bias"], beta=1.0)

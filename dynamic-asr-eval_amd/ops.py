@@ -90,9 +90,11 @@ def workspace(device=None):
 
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
-         nb1=1, nb2=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, split_k=0, force=None, c_in=None):
+         nb1=1, nb2=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, split_k=0, force=None, c_in=None,
+         epilogue=0, aux=None):
     """Raw strided batched GEMM (see dyn_gemm_desc). Offsets are in elements from each tensor's data_ptr.
-    `force=(tile_m, tile_n, tail_slices)` pins the kernel configuration (autotuner / tests)."""
+    `force=(tile_m, tile_n, tail_slices)` pins the kernel configuration (autotuner / tests).
+    `epilogue`: 0 none, EPI_SILU (C = silu(v), aux = v if given), EPI_SILU_GRAD (C = v * silu'(aux)); aux addressed like C."""
     _chk(a, "gemm.A"); _chk(b, "gemm.B"); _chk(c, "gemm.C")
     d = GemmDesc()
     if force is not None:
@@ -107,6 +109,8 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha
     d.C_in = (c_in.data_ptr() + 4 * c_off) if c_in is not None else None   # residual source (same addressing as C)
     d.nb1, d.nb2 = nb1, nb2
     d.split_k = split_k
+    d.epilogue = int(epilogue)
+    d.aux = (aux.data_ptr() + 4 * c_off) if aux is not None else None
     ws = workspace(c.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     prof = GEMM_PROFILE
@@ -123,6 +127,52 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha
             return c
     check(_L().dyn_gemm_f32(ctypes.byref(d), _stream()), "dyn_gemm_f32")
     return c
+
+
+EPI_SILU, EPI_SILU_GRAD = 1, 2
+
+
+def wgrad_desc(dy, x, dw, alpha=1.0, beta=1.0, colsum=None, colsum_beta=1.0):
+    """Descriptor of dw[N, K] = alpha * dy[M, N]^T @ x[M, K] + beta * dw for gemm_grouped; `colsum` [N] also receives
+    colsum_beta * colsum + column sums of dy (the bias gradient).  The tensors must stay alive and unmodified until the launch."""
+    _cc(dy, "wgrad.dy"); _cc(x, "wgrad.x"); _cc(dw, "wgrad.dw")
+    N, K = dw.shape
+    M = dy.numel() // N
+    d = GemmDesc()
+    d.trans_a, d.trans_b = 1, 0
+    d.M, d.N, d.K = N, K, M
+    d.alpha, d.beta = alpha, beta
+    d.A, d.lda = dy.data_ptr(), N
+    d.B, d.ldb = x.data_ptr(), K
+    d.C, d.ldc = dw.data_ptr(), K
+    d.nb1 = d.nb2 = 1
+    if colsum is not None:
+        _cc(colsum, "wgrad.colsum")
+        d.a_colsum, d.a_colsum_beta = colsum.data_ptr(), colsum_beta
+    d._keep = (dy, x, dw, colsum)
+    return d
+
+
+def gemm_grouped(descs):
+    """One launch over the 128x128 tiles of all `descs` (dyn_gemm_f32_grouped): the deferred weight gradients of a backward pass."""
+    n = len(descs)
+    if n == 0:
+        return
+    arr = (GemmDesc * n)(*descs)
+    ws = workspace()
+    prof = GEMM_PROFILE
+    fl = sum(2.0 * d.M * d.N * d.K for d in descs)
+    if prof is not None:
+        prof["calls"] += 1
+        prof["flops"] += fl
+        prof["bytes"] += sum(4.0 * (d.M * d.K + d.K * d.N + 2 * d.M * d.N) for d in descs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_L().dyn_gemm_f32_grouped(arr, n, ws.data_ptr(), ws.numel(), _stream()), "dyn_gemm_f32_grouped")
+        e1.record()
+        prof["samples_excl" if prof.get("exclusive_now") else "samples"].append((fl, e0, e1))
+        return
+    check(_L().dyn_gemm_f32_grouped(arr, n, ws.data_ptr(), ws.numel(), _stream()), "dyn_gemm_f32_grouped")
 
 
 GEMM_PROFILE = None
@@ -182,8 +232,9 @@ def gemm_profile_stop():
     return out
 
 
-def linear(x, w, bias=None, out=None, alpha=1.0, beta=0.0, residual=None):
-    """out[M, N] = alpha * x[M, K] @ w[N, K]^T + beta * (residual if given else out) + bias   (torch.nn.Linear layout)."""
+def linear(x, w, bias=None, out=None, alpha=1.0, beta=0.0, residual=None, epilogue=0, aux=None):
+    """out[M, N] = alpha * x[M, K] @ w[N, K]^T + beta * (residual if given else out) + bias   (torch.nn.Linear layout);
+    with epilogue=EPI_SILU: out = silu(that) and aux (if given) = that."""
     _cc(x, "linear.x"); _cc(w, "linear.w")
     K = x.shape[-1]
     M = x.numel() // K
@@ -192,18 +243,19 @@ def linear(x, w, bias=None, out=None, alpha=1.0, beta=0.0, residual=None):
     if out is None:
         assert beta == 0.0 or residual is not None
         out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=F32)
-    return gemm(x, w, out, trans_b=True, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, alpha=alpha, beta=beta, c_in=residual)
+    return gemm(x, w, out, trans_b=True, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, alpha=alpha, beta=beta, c_in=residual,
+                epilogue=epilogue, aux=aux)
 
 
-def linear_dgrad(dy, w, out=None, alpha=1.0, beta=0.0):
-    """dx[M, K] = alpha * dy[M, N] @ w[N, K] + beta * dx."""
+def linear_dgrad(dy, w, out=None, alpha=1.0, beta=0.0, epilogue=0, aux=None):
+    """dx[M, K] = alpha * dy[M, N] @ w[N, K] + beta * dx; with epilogue=EPI_SILU_GRAD: dx *= silu'(aux) (aux = the pre-activation)."""
     _cc(dy, "linear_dgrad.dy"); _cc(w, "linear_dgrad.w")
     N, K = w.shape
     M = dy.numel() // N
     if out is None:
         assert beta == 0.0
         out = torch.empty(*dy.shape[:-1], K, device=dy.device, dtype=F32)
-    return gemm(dy, w, out, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, alpha=alpha, beta=beta)
+    return gemm(dy, w, out, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, alpha=alpha, beta=beta, epilogue=epilogue, aux=aux)
 
 
 def linear_wgrad(dy, x, dw, alpha=1.0, beta=1.0):
@@ -322,11 +374,18 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     return out, mean, rstd
 
 
-def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, dx_beta=0.0, wgrad_beta=1.0):
+def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, dx_beta=0.0, wgrad_beta=1.0, dx_in=None):
+    """dx = norm_bwd(dy) + dx_beta * (dx_in if given else dx)."""
     _cc(x, "layernorm_bwd.x"); _cc(dy, "layernorm_bwd.dy"); _cc(dx, "layernorm_bwd.dx")
     C = x.shape[-1]
     rows = x.numel() // C
     ws = workspace(x.device)
+    if dx_in is not None:
+        _cc(dx_in, "layernorm_bwd.dx_in")
+        check(_L().dyn_layernorm_bwd_res(x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx_in.data_ptr(),
+                                         dx.data_ptr(), dx_beta, _opt(dgamma, "dgamma"), _opt(dbeta, "dbeta"), wgrad_beta, rows, C,
+                                         ws.data_ptr(), ws.numel(), _stream()), "dyn_layernorm_bwd_res")
+        return dx
     check(_L().dyn_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(),
                                  dx.data_ptr(), dx_beta, _opt(dgamma, "dgamma"), _opt(dbeta, "dbeta"), wgrad_beta, rows, C,
                                  ws.data_ptr(), ws.numel(), _stream()), "dyn_layernorm_bwd")

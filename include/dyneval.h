@@ -60,10 +60,26 @@ typedef struct {
     /* optional residual source: C = alpha*A@B + beta*C_in (+ bias), C_in addressed exactly like C (same ldc / batch
      * strides); NULL = accumulate in place.  Lets `x_new = x + f(x)` keep x intact for the backward without a copy. */
     const float* C_in;
+    /* activation fused into the store of C (v = alpha*A@B + beta*C_in + bias):
+     *   0 none;  1 C = silu(v) and, if aux != NULL, aux = v (the pre-activation the backward needs);  2 C = v * silu'(aux)
+     * aux is addressed exactly like C.  Replaces the separate SiLU kernels around the FFN products (the `F.silu` between the two
+     * FFN linears inside model(audio_signal=...) and its autograd backward, reference lcasr/lib.py:550,579). */
+    int32_t epilogue, reserved2_;
+    float* aux;
+    /* grouped launches only (dyn_gemm_f32_grouped, trans_a): a_colsum[m] = a_colsum_beta * a_colsum[m] + sum_k A(k, m), i.e. the bias
+     * gradient of the linear layer whose weight gradient this product is, summed from the A panel the product streams anyway. */
+    float* a_colsum;
+    float a_colsum_beta, reserved3_;
 } dyn_gemm_desc;
 
 int64_t dyn_gemm_f32_workspace_bytes(const dyn_gemm_desc* d);
 int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream);
+/* n <= 96 independent products (same trans flags, no batching / split-K / bias / activation) as ONE launch over all their 128x128
+ * tiles: the weight-gradient products of a whole backward pass (`loss.backward()`, reference lcasr/lib.py:579), each of which alone
+ * has too few tiles to fill 256 CUs.  `descs` is a HOST array; the descriptor table is rebuilt in `workspace` by a kernel taking it
+ * as arguments (hipGraph-capturable).  Outputs must not alias each other.  Deterministic (no atomics, fixed summation order). */
+int64_t dyn_gemm_f32_grouped_workspace_bytes(int32_t n);
+int dyn_gemm_f32_grouped(const dyn_gemm_desc* descs, int32_t n, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HBM-bound encoder pieces (activations, norms, softmax, convolutions).  All replace ops inside
@@ -94,6 +110,12 @@ int dyn_layernorm_fwd(const float* x, const float* gamma, const float* beta, flo
 int dyn_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
                       float dx_beta, float* dgamma, float* dbeta, float wgrad_beta, int64_t rows, int64_t C,
                       void* workspace, int64_t workspace_bytes, void* stream);
+/* same, out of place: dx = norm_bwd(dy) + dx_beta * dx_in.  The residual-stream gradient of a block gets a NEW buffer per module,
+ * so the previous one stays intact as the A operand of the weight-gradient products deferred to the end of the backward
+ * (dyn_gemm_f32_grouped). */
+int dyn_layernorm_bwd_res(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy,
+                          const float* dx_in, float* dx, float dx_beta, float* dgamma, float* dbeta, float wgrad_beta,
+                          int64_t rows, int64_t C, void* workspace, int64_t workspace_bytes, void* stream);
 int dyn_rmsnorm_fwd(const float* x, const float* gamma, float* y, float* rstd, int64_t rows, int64_t C, float eps,
                     void* stream);
 int dyn_rmsnorm_bwd(const float* x, const float* gamma, const float* rstd, const float* dy, float* dx, float dx_beta,

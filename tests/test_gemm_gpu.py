@@ -106,3 +106,55 @@ def test_gemm_direct_to_lds_matches_register_staged_bitwise(cuda):
     buf_b = torch.empty(N * K + 1, device=cuda); buf_b[1:].copy_(b.flatten())
     ops.gemm(buf_a, buf_b, c2, trans_b=True, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_off=1, b_off=1, force=(128, 128, 1))
     assert torch.equal(c1, c2)
+
+
+def test_grouped_weight_gradients_match_single_launches_and_sum_the_bias(cuda):
+    """dyn_gemm_f32_grouped: the deferred weight-gradient products of a backward pass as ONE launch over all their 128x128 tiles.
+    Each group must equal the single-GEMM launch with the same tile and no K split bit for bit (same MFMA order), accumulate into
+    dW with beta = 1, and the fused column sums of dy (the bias gradient) must match float64; K % 32 != 0 takes the register-staged
+    path, as the short last window of a recording does (T' = 1992)."""
+    from dynamic_asr_eval_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for tokens in (2048, 1992, 100):
+        shapes = [(3072, 768), (768, 3072), (2304, 768), (768, 768), (1536, 768), (256, 40), (132, 260)]
+        descs, want, sums, outs, biases = [], [], [], [], []
+        for n_out, k_in in shapes:
+            dy = (torch.rand(tokens, n_out, generator=g) - 0.5).to(cuda)
+            x = (torch.rand(tokens, k_in, generator=g) - 0.5).to(cuda)
+            dw0 = (torch.rand(n_out, k_in, generator=g) - 0.5).to(cuda)
+            b0 = (torch.rand(n_out, generator=g) - 0.5).to(cuda)
+            single = dw0.clone()
+            ops.gemm(dy, x, single, trans_a=True, M=n_out, N=k_in, K=tokens, lda=n_out, ldb=k_in, ldc=k_in, alpha=0.5, beta=1.0,
+                     force=(128, 128, 1), split_k=1)
+            want.append(single)
+            sums.append(b0.double() + dy.double().sum(0))
+            dw, b = dw0.clone(), b0.clone()
+            outs.append(dw); biases.append(b)
+            descs.append(ops.wgrad_desc(dy, x, dw, alpha=0.5, beta=1.0, colsum=b if n_out != 1536 else None, colsum_beta=1.0))
+        ops.gemm_grouped(descs)
+        for (n_out, k_in), dw, w, b, sref in zip(shapes, outs, want, biases, sums):
+            assert torch.equal(dw, w), (tokens, n_out, k_in, (dw - w).abs().max().item())
+            if n_out != 1536:
+                assert (b.double() - sref).abs().max().item() < 2e-4, (tokens, n_out)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 3072, 768), (2048, 3072, 768), (2040, 2560, 256), (77, 100, 64)])
+def test_silu_epilogues_equal_the_separate_kernels(cuda, M, N, K):
+    """epilogue EPI_SILU (C = silu(v), aux = v) and EPI_SILU_GRAD (C = v * silu'(aux)) against GEMM + dyn_silu_fwd / dyn_silu_bwd:
+    same formulas, so the results agree bit for bit whatever plan (split-K, tail slices, edge tiles) the shape gets."""
+    from dynamic_asr_eval_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.rand(M, K, generator=g) - 0.5).to(cuda)
+    w = (torch.rand(N, K, generator=g) - 0.5).to(cuda)
+    bias = (torch.rand(N, generator=g) - 0.5).to(cuda)
+    u_ref = ops.linear(x, w, bias)
+    a_ref = ops.silu(u_ref)
+    u = torch.empty_like(u_ref)
+    a = ops.linear(x, w, bias, epilogue=ops.EPI_SILU, aux=u)
+    assert torch.equal(u, u_ref) and torch.equal(a, a_ref)
+    assert torch.equal(ops.linear(x, w, bias, epilogue=ops.EPI_SILU), a_ref)          # no-grad form: the pre-activation is not kept
+    dy = (torch.rand(M, N, generator=g) - 0.5).to(cuda)
+    pre = (torch.rand(M, K, generator=g) * 6 - 3).to(cuda)
+    d_ref = ops.silu_bwd(pre, ops.linear_dgrad(dy, w, alpha=0.5))
+    d = ops.linear_dgrad(dy, w, alpha=0.5, epilogue=ops.EPI_SILU_GRAD, aux=pre)
+    assert torch.equal(d, d_ref)

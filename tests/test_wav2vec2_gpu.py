@@ -98,6 +98,8 @@ def _base_pair(cuda, seed=0):
         for n, p in ref.named_parameters():
             if p.dim() == 1 or "original0" in n:
                 p.add_(0.1 * torch.randn_like(p))
+        ref.lm_head.bias[0] += 1.0     # favour the CTC blank (<pad> = 0): a seeded model otherwise labels nearly every frame and the
+                                       # pseudo-label no longer fits the 409 frames (infinite CTC loss, in the reference too)
     hip = Wav2Vec2ForCTC(cfg, device=cuda)
     hip.load_state_dict(ref.state_dict(), strict=False)
     assert abs(sum(p.numel() for p in hip.parameters()) - sum(p.numel() for p in ref.parameters())) <= cfg.hidden_size   # masked_spec_embed
@@ -174,7 +176,7 @@ def test_chunked_dynamic_eval_at_the_reference_window(cuda, base_pair):
     args = argparse.Namespace(epochs=1, shuffle=False)
     want = dynamic_eval_chunked_ref(args, ref, wav, 131072, 0, tok, MADGRAD_REF, lr_args={'lr': 1e-6})
     got = W.dynamic_eval(args, hip, wav, 131072, 0, tok, None, use_tqdm=False, optim=W.MADGRAD, lr_args={'lr': 1e-6})
-    assert got.shape == want.shape == (409 + 58, 32)
+    assert got.shape == want.shape == (409 + 58, 32) and np.isfinite(want).all(), "the oracle itself must produce a finite result"
     err = np.abs(got - want).max()
     bad = got.argmax(-1) != want.argmax(-1)
     top2 = np.sort(want, -1)[:, -2:]
