@@ -140,8 +140,12 @@ def test_grouped_weight_gradients_match_single_launches_and_sum_the_bias(cuda):
 
 @pytest.mark.parametrize("M,N,K", [(4096, 3072, 768), (2048, 3072, 768), (2040, 2560, 256), (77, 100, 64)])
 def test_silu_epilogues_equal_the_separate_kernels(cuda, M, N, K):
-    """epilogue EPI_SILU (C = silu(v), aux = v) and EPI_SILU_GRAD (C = v * silu'(aux)) against GEMM + dyn_silu_fwd / dyn_silu_bwd:
-    same formulas, so the results agree bit for bit whatever plan (split-K, tail slices, edge tiles) the shape gets."""
+    """epilogue EPI_SILU (C = silu(v), aux = v) and EPI_SILU_GRAD (C = v * silu'(aux)) against GEMM + dyn_silu_fwd / dyn_silu_bwd,
+    whatever plan (split-K, tail slices, edge tiles) the shape gets: the pre-activation is bit-identical, the activation agrees to
+    the last bit or two (same formula; the compiler schedules the reciprocal differently inside the GEMM epilogue)."""
+    def close(a, b):
+        return (a - b).abs().max().item() <= 5e-7 * max(1.0, b.abs().max().item())
+
     from dynamic_asr_eval_amd import ops
     g = torch.Generator().manual_seed(M + N)
     x = (torch.rand(M, K, generator=g) - 0.5).to(cuda)
@@ -151,10 +155,10 @@ def test_silu_epilogues_equal_the_separate_kernels(cuda, M, N, K):
     a_ref = ops.silu(u_ref)
     u = torch.empty_like(u_ref)
     a = ops.linear(x, w, bias, epilogue=ops.EPI_SILU, aux=u)
-    assert torch.equal(u, u_ref) and torch.equal(a, a_ref)
-    assert torch.equal(ops.linear(x, w, bias, epilogue=ops.EPI_SILU), a_ref)          # no-grad form: the pre-activation is not kept
+    assert torch.equal(u, u_ref) and close(a, a_ref)
+    assert torch.equal(ops.linear(x, w, bias, epilogue=ops.EPI_SILU), a)          # no-grad form: the pre-activation is not kept
     dy = (torch.rand(M, N, generator=g) - 0.5).to(cuda)
     pre = (torch.rand(M, K, generator=g) * 6 - 3).to(cuda)
     d_ref = ops.silu_bwd(pre, ops.linear_dgrad(dy, w, alpha=0.5))
     d = ops.linear_dgrad(dy, w, alpha=0.5, epilogue=ops.EPI_SILU_GRAD, aux=pre)
-    assert torch.equal(d, d_ref)
+    assert close(d, d_ref)
