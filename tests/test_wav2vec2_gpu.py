@@ -196,7 +196,7 @@ def test_run_wav2vec2_harness(cuda, tmp_path, capsys):
         out = capsys.readouterr().out
         assert "Loaded model from" in out and "Total number of parameters: 94." in out and f"WER: {wer}" in out
     lines = open(log).read().strip().split("\n")
-    assert len(lines) == 2 and all("\t overlap: 0\t seq_len: 131072\t WER: " in l for l in lines)
+    assert len(lines) == 2 and all("overlap: 0\t seq_len: 131072\t WER: " in l for l in lines)
     torch.manual_seed(0)
     ck = str(tmp_path / "hf.pt")
     torch.save(HF(Wav2Vec2Config()).state_dict(), ck)
