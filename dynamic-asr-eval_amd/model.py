@@ -144,8 +144,11 @@ class SCConformerXL:
         self._ctx_static = False
         self._ctx_key = None
         self.fused_convmod = True   # GLU + dwconv + norm + SiLU in one kernel (csrc/convmod.hip)
-        self.fused_silu = True      # SiLU / SiLU' inside the epilogue of the GEMM that produces its argument (dyn_gemm_desc.epilogue)
-        self.grouped_wgrad = True   # block weight gradients deferred to ONE grouped launch at the end of the backward (+ bias sums)
+        import os
+        # A/B switches (measurements only): DYN_FUSED_SILU=0 / DYN_GROUPED_WGRAD=0 restore the separate kernels / launches
+        self.fused_silu = os.environ.get("DYN_FUSED_SILU", "1") != "0"        # SiLU / SiLU' in the epilogue of the producing GEMM
+        self.grouped_wgrad = os.environ.get("DYN_GROUPED_WGRAD", "1") != "0"  # block weight gradients deferred to ONE grouped launch
+                                                                              # at the end of the backward (+ bias column sums)
         self._wq = None
         self.training = False
 
