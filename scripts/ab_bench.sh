@@ -9,7 +9,7 @@ python bench.py --steps 3 --warmup 0 --prewarm_s 30 --no_cpu_baseline --side_ste
 for r in $(seq 1 $ROUNDS); do
   for cfg in "$@"; do
     name=${cfg%%:*}; envs=${cfg#*:}
-    ( IFS=','; for e in $envs; do [ -n "$e" ] && export "$e"; done; python bench.py $ARGS > "$out/${name}_$r.json" 2>/dev/null )
+    ( for e in ${envs//,/ }; do export "$e"; done; python bench.py $ARGS > "$out/${name}_$r.json" 2> "$out/${name}_$r.err" )
     python - "$out/${name}_$r.json" "$name" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
