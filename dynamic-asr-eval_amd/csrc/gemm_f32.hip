@@ -62,6 +62,7 @@ struct KParams {
     int epi;             // DYN_GEMM_EPI_*: 0 none; 1 C = silu(v), aux = v (pre-activation kept for the backward); 2 C = v * silu'(aux)
     float* aux;          // addressed like C (same ldc / batch strides)
     // grouped launches only
+    int* counters;       // arrival counters of the partial tiles (zero before and after every launch); NULL = separate reduce kernels
     float* colsum;       // [M]: colsum[m] = colsum_beta * colsum[m] + sum_k A(m, k)   (bias gradient of a weight-gradient GEMM)
     float colsum_beta;
     int64_t first_item;  // first work item of this group in the grouped launch
@@ -405,8 +406,42 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
         }
     }
     // Epilogue. C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    if (is_tail) {
-        float* W = p.tail_ws + ((item - p.full_items) * p.tail_f + sub) * (int64_t)(BM * BN);
+    const bool partial = !GROUPED && (is_tail || p.splits > 1);
+    if (partial && p.counters == nullptr) {       // legacy: slabs now, a second kernel sums them
+        if (is_tail) {
+            float* W = p.tail_ws + ((item - p.full_items) * p.tail_f + sub) * (int64_t)(BM * BN);
+#pragma unroll
+            for (int a = 0; a < WTM; ++a)
+#pragma unroll
+                for (int b = 0; b < WTN; ++b) {
+                    float* wp = W + (wm * (BM / 2) + a * 32 + 4 * h) * BN + wn * (BN / 2) + b * 32 + i;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) wp[((e & 3) + 8 * (e >> 2)) * BN] = acc[a][b][e];
+                }
+        } else {
+            float* W = p.ws + ((int64_t)ks * p.nbatch + zb) * p.M * p.N;
+#pragma unroll
+            for (int a = 0; a < WTM; ++a)
+#pragma unroll
+                for (int b = 0; b < WTN; ++b) {
+                    const int64_t col = n0 + wn * (BN / 2) + b * 32 + i;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int64_t row = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (row < p.M && col < p.N) W[row * p.N + col] = acc[a][b][e];
+                    }
+                }
+        }
+        return;
+    }
+    if (partial) {
+        // K slice `sl` of `nsl` of partial tile `pt`: store the slab, take a ticket; the workgroup that arrives LAST sums all
+        // slabs of the tile in slice order (fixed order: the result does not depend on who is last) and runs the epilogue.
+        const int64_t pt = is_tail ? (item - p.full_items) : t2;
+        const int sl = is_tail ? sub : ks;
+        const int nsl = is_tail ? p.tail_f : p.splits;
+        float* W0 = p.tail_ws + pt * nsl * (int64_t)(BM * BN);
+        float* W = W0 + (int64_t)sl * (BM * BN);
 #pragma unroll
         for (int a = 0; a < WTM; ++a)
 #pragma unroll
@@ -415,20 +450,29 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #pragma unroll
                 for (int e = 0; e < 16; ++e) wp[((e & 3) + 8 * (e >> 2)) * BN] = acc[a][b][e];
             }
-    } else if (p.splits > 1) {
-        float* W = p.ws + ((int64_t)ks * p.nbatch + zb) * p.M * p.N;
+        __threadfence();                       // release the slab at device scope (other XCDs have other L2s)
+        __syncthreads();                       // every wave's stores are fenced; all LDS fragment reads are long done
+        int* flag = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) flag[0] = (atomicAdd(&p.counters[pt], 1) == nsl - 1) ? 1 : 0;
+        __syncthreads();
+        if (flag[0] == 0) return;
+        __threadfence();                       // acquire the other slices' slabs
 #pragma unroll
         for (int a = 0; a < WTM; ++a)
 #pragma unroll
             for (int b = 0; b < WTN; ++b) {
-                const int64_t col = n0 + wn * (BN / 2) + b * 32 + i;
+                const float* rp = W0 + (wm * (BM / 2) + a * 32 + 4 * h) * BN + wn * (BN / 2) + b * 32 + i;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int64_t row = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (row < p.M && col < p.N) W[row * p.N + col] = acc[a][b][e];
+                    const float* q = rp + ((e & 3) + 8 * (e >> 2)) * BN;
+                    float t = q[0];
+                    for (int k = 1; k < nsl; ++k) t += q[(int64_t)k * (BM * BN)];
+                    acc[a][b][e] = t;
                 }
             }
-    } else if (m0 + BM <= p.M && n0 + BN <= p.N) {  // interior tile: unguarded stores
+        if (threadIdx.x == 0) p.counters[pt] = 0;     // ready for the next launch on this stream
+    }
+    if (m0 + BM <= p.M && n0 + BN <= p.N) {  // interior tile: unguarded stores
         float* C = p.C + z1 * p.sc1 + z2 * p.sc2;
 #pragma unroll
         for (int a = 0; a < WTM; ++a)
@@ -621,7 +665,7 @@ bool eval_config(const dyn_gemm_desc* d, int bm, int bn, int s, int f_req, Plan*
     if (f > 1) t += 2e-6 + (double)f * rem * bm * bn * 4.0 * 2.0 / 3.0e12;
     *cost = t;
     out->bm = bm; out->bn = bn; out->splits = s_eff; out->kchunk = kchunk;
-    out->ws_bytes = s_eff > 1 ? (int64_t)s_eff * batch * d->M * d->N * (int64_t)sizeof(float) : 0;
+    out->ws_bytes = s_eff > 1 ? (int64_t)s_eff * batch * tiles * bm * bn * (int64_t)sizeof(float) : 0;   // tile-local slabs (>= the dense layout)
     out->tail_f = f;
     out->tail_items = f > 1 ? rem : 0;
     out->full_items = items - out->tail_items;
@@ -743,6 +787,10 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
     kp.tail_f = pl.tail_f;
     kp.tail_ws = (float*)d->workspace;
     kp.epi = d->epilogue; kp.aux = d->aux;
+    // in-kernel combine of K slices: needs one zeroed arrival counter per partial tile
+    const int64_t n_ptiles = pl.splits > 1 ? tiles_m * tiles_n * batch : pl.tail_items;
+    static const bool allow_ticket = [] { const char* e = getenv("DYN_GEMM_TICKET"); return !e || atoi(e) != 0; }();
+    kp.counters = (allow_ticket && d->counters && n_ptiles > 0 && n_ptiles <= d->n_counters) ? d->counters : nullptr;
     kp.colsum = nullptr; kp.colsum_beta = 0.f; kp.first_item = 0;
     const int64_t nblocks = pl.full_items + pl.tail_items * pl.tail_f;
     DYN_REQUIRE(nblocks < (1ll << 31) && tiles_m * tiles_n < (1ll << 31), DYN_E_ARG, "dyn_gemm_f32: grid too large (%lld workgroups)",
@@ -758,6 +806,7 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
     else launch_tile<true, true>(kp, pl, vec, grid, st);
     int rc = dyn::check_launch("dyn_gemm_f32");
     if (rc != DYN_OK) return rc;
+    if (kp.counters != nullptr) return rc;      // the last-arriving workgroup of every partial tile has already written C
     if (pl.splits > 1) {
         const int64_t total = d->M * d->N * batch;
         int64_t nblk = dyn::cdiv(total, 256);
@@ -817,7 +866,7 @@ extern "C" int dyn_gemm_f32_grouped(const dyn_gemm_desc* descs, int32_t n, void*
         kp.n_major = 0;       // row-major runs of tiles: consecutive tiles share the A panel (dy), the operand the bias sums also read
         kp.tiles_per_batch = (int64_t)kp.tiles_m * kp.tiles_n;
         kp.full_items = kp.tiles_per_batch; kp.tail_f = 1; kp.tail_ws = nullptr;
-        kp.epi = 0; kp.aux = nullptr;
+        kp.epi = 0; kp.aux = nullptr; kp.counters = nullptr;
         kp.colsum = d->a_colsum; kp.colsum_beta = d->a_colsum_beta;
         kp.first_item = total;
         total += kp.tiles_per_batch;

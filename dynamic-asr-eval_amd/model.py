@@ -146,7 +146,9 @@ class SCConformerXL:
         self.fused_convmod = True   # GLU + dwconv + norm + SiLU in one kernel (csrc/convmod.hip)
         import os
         # A/B switches (measurements only): DYN_FUSED_SILU=0 / DYN_GROUPED_WGRAD=0 restore the separate kernels / launches
-        self.fused_silu = os.environ.get("DYN_FUSED_SILU", "1") != "0"        # SiLU / SiLU' in the epilogue of the producing GEMM
+        self.fused_silu = os.environ.get("DYN_FUSED_SILU", "0") != "0"        # SiLU / SiLU' in the epilogue of the producing GEMM: OFF
+        # by default (A/B on one box, 3 chains: 739 vs 738 audio-s/s, while the GEMM's own rate drops 110 -> 101 TFLOP/s: the
+        # activation runs with the MFMA pipe idle, whereas the separate HBM-bound kernels hide under the other chains' GEMMs)
         self.grouped_wgrad = os.environ.get("DYN_GROUPED_WGRAD", "1") != "0"  # block weight gradients deferred to ONE grouped launch
                                                                               # at the end of the backward (+ bias column sums)
         self._wq = None
@@ -250,6 +252,7 @@ class SCConformerXL:
     def _scratch(self):
         if self._ws is None:
             self._ws = torch.empty(ops.WORKSPACE_BYTES, dtype=torch.uint8, device=self.device)
+            ops.counters(self._ws)          # zeroed arrival counters of this replica's GEMMs, allocated outside any graph capture
         return self._ws
 
     def forward(self, audio_signal):

@@ -85,13 +85,29 @@ def workspace(device=None):
     if ws is None:
         ws = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
         _WS[key] = ws
+        counters(ws)
     return ws
+
+
+_COUNTERS = {}
+N_COUNTERS = 16384
+
+
+def counters(ws):
+    """Arrival counters of the GEMM's in-kernel K-slice combine, one zeroed int32 buffer per scratch buffer (so per model replica /
+    stream: concurrent chains never share them)."""
+    key = ws.data_ptr()
+    c = _COUNTERS.get(key)
+    if c is None:
+        c = torch.zeros(N_COUNTERS, dtype=torch.int32, device=ws.device)
+        _COUNTERS[key] = c
+    return c
 
 
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
          nb1=1, nb2=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, split_k=0, force=None, c_in=None,
-         epilogue=0, aux=None):
+         epilogue=0, aux=None, ticket=True):
     """Raw strided batched GEMM (see dyn_gemm_desc). Offsets are in elements from each tensor's data_ptr.
     `force=(tile_m, tile_n, tail_slices)` pins the kernel configuration (autotuner / tests).
     `epilogue`: 0 none, EPI_SILU (C = silu(v), aux = v if given), EPI_SILU_GRAD (C = v * silu'(aux)); aux addressed like C."""
@@ -113,6 +129,9 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha
     d.aux = (aux.data_ptr() + 4 * c_off) if aux is not None else None
     ws = workspace(c.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    if ticket:       # in-kernel combine of K slices (False: the separate reduce pass; tests compare the two)
+        cnt = counters(ws)
+        d.counters, d.n_counters = cnt.data_ptr(), cnt.numel()
     prof = GEMM_PROFILE
     if prof is not None:
         prof["calls"] += 1

@@ -70,6 +70,12 @@ typedef struct {
      * gradient of the linear layer whose weight gradient this product is, summed from the A panel the product streams anyway. */
     float* a_colsum;
     float a_colsum_beta, reserved3_;
+    /* optional: n_counters int32 arrival counters owned by the caller, ZERO before the first call and left zero by every call
+     * (do not share them between streams).  With them the K slices of a split / tail-sliced product are combined inside the
+     * kernel by the workgroup that arrives last (slices summed in slice order: same bits as the separate reduce pass, which is
+     * used when counters == NULL or there are fewer counters than partial tiles). */
+    int32_t* counters;
+    int64_t n_counters;
 } dyn_gemm_desc;
 
 int64_t dyn_gemm_f32_workspace_bytes(const dyn_gemm_desc* d);

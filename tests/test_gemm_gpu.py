@@ -162,3 +162,33 @@ def test_silu_epilogues_equal_the_separate_kernels(cuda, M, N, K):
     d_ref = ops.silu_bwd(pre, ops.linear_dgrad(dy, w, alpha=0.5))
     d = ops.linear_dgrad(dy, w, alpha=0.5, epilogue=ops.EPI_SILU_GRAD, aux=pre)
     assert close(d, d_ref)
+
+
+@pytest.mark.parametrize("mode,M,N,K,nb,force,split", [("NT", 4096, 2304, 768, 1, (128, 128, 4), 0), ("TN", 768, 3072, 2048, 1, (64, 64, 1), 3),
+                                                       ("NN", 2048, 768, 3072, 1, (64, 64, 2), 0), ("NT", 1992, 1992, 128, 12, (128, 64, 8), 0),
+                                                       ("TN", 256, 256, 20480, 1, (64, 64, 1), 12), ("NT", 1000, 900, 300, 2, (64, 128, 3), 0)])
+def test_in_kernel_slice_combine_equals_the_reduce_pass(cuda, mode, M, N, K, nb, force, split):
+    """K slices (global split-K or the K-sliced tail round) combined inside the kernel by the last-arriving workgroup (ordered
+    ticket, slices summed in slice order) == slabs + the separate reduce kernel, bit for bit, with bias / beta / residual source;
+    the arrival counters are back at zero afterwards, so the next launch (and a hipGraph replay) starts clean."""
+    from dynamic_asr_eval_amd import ops
+    ta, tb = mode[0] == "T", mode[1] == "T"
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.rand((nb, K, M) if ta else (nb, M, K), generator=g) - 0.5).to(cuda)
+    b = (torch.rand((nb, N, K) if tb else (nb, K, N), generator=g) - 0.5).to(cuda)
+    c0 = (torch.rand(nb, M, N, generator=g) - 0.5).to(cuda)
+    res = (torch.rand(nb, M, N, generator=g) - 0.5).to(cuda)
+    bias = (torch.rand(N, generator=g) - 0.5).to(cuda)
+
+    def run(ticket):
+        c = c0.clone()
+        ops.gemm(a, b, c, trans_a=ta, trans_b=tb, M=M, N=N, K=K, lda=a.shape[2], ldb=b.shape[2], ldc=N, nb1=nb, sa=(a.shape[1] * a.shape[2], 0),
+                 sb=(b.shape[1] * b.shape[2], 0), sc=(M * N, 0), alpha=0.7, beta=0.3, bias=bias, c_in=res, force=force, split_k=split, ticket=ticket)
+        return c
+
+    want = run(False)
+    for _ in range(3):
+        assert torch.equal(run(True), want)
+    assert int(ops.counters(ops.workspace(cuda)).abs().sum().item()) == 0
+    ref = 0.7 * ((a.transpose(1, 2) if ta else a).double() @ (b.transpose(1, 2) if tb else b).double()) + 0.3 * res.double() + bias.double()
+    assert (want.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
