@@ -68,6 +68,14 @@ struct KParams {
     int64_t first_item;  // first work item of this group in the grouped launch
 };
 
+// alpha * acc + beta * c_in + bias in ONE pinned operation order (explicit mul / fma / add: no contraction differences between the
+// tile epilogue and the reduce kernels, so every plan of a product rounds its outputs the same way)
+__device__ __forceinline__ float epi_value(float alpha, float acc, float beta, const float* cin, float bias) {
+    float v = __fmul_rn(alpha, acc);
+    if (beta != 0.f) v = __fmaf_rn(beta, *cin, v);
+    return __fadd_rn(v, bias);
+}
+
 // same formulas as silu_fwd_kernel / silu_bwd_kernel (elementwise.hip): fused and unfused paths agree bit for bit
 __device__ __forceinline__ float silu_f(float v) { return v * dyn::sigmoidf_(v); }
 __device__ __forceinline__ float silu_grad_f(float u) {
@@ -486,8 +494,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         float* q2 = cp + (int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc;
-                        float v = p.alpha * acc[a][b][e] + bv;
-                        if (p.beta != 0.f) v += p.beta * q2[p.cin_delta];
+                        const float v = epi_value(p.alpha, acc[a][b][e], p.beta, q2 + p.cin_delta, bv);
                         if (p.epi == 1) { if (p.aux) q2[ad] = v; *q2 = silu_f(v); }
                         else *q2 = v * silu_grad_f(q2[ad]);
                     }
@@ -495,11 +502,11 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         float* q2 = cp + (int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc;
-                        *q2 = p.alpha * acc[a][b][e] + p.beta * q2[p.cin_delta] + bv;
+                        *q2 = epi_value(p.alpha, acc[a][b][e], p.beta, q2 + p.cin_delta, bv);
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) cp[(int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc] = p.alpha * acc[a][b][e] + bv;
+                    for (int e = 0; e < 16; ++e) cp[(int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc] = epi_value(p.alpha, acc[a][b][e], 0.f, nullptr, bv);
                 }
             }
     } else {
@@ -514,8 +521,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
                 for (int e = 0; e < 16; ++e) {
                     const int64_t row = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (row < p.M && col < p.N) {
-                        float v = p.alpha * acc[a][b][e] + bv;
-                        if (p.beta != 0.f) v += p.beta * C[row * p.ldc + col + p.cin_delta];
+                        float v = epi_value(p.alpha, acc[a][b][e], p.beta, C + row * p.ldc + col + p.cin_delta, bv);
                         if (p.epi == 1) { if (p.aux) C[row * p.ldc + col + (p.aux - p.C)] = v; v = silu_f(v); }
                         else if (p.epi == 2) v *= silu_grad_f(C[row * p.ldc + col + (p.aux - p.C)]);
                         C[row * p.ldc + col] = v;
@@ -574,9 +580,7 @@ __global__ void splitk_reduce_kernel(const KParams p) {
         for (int k = 0; k < p.splits; ++k) s += p.ws[((int64_t)k * p.nbatch + zb) * mn + rem];
         const int64_t z1 = zb / p.nb2, z2 = zb % p.nb2;
         float* C = p.C + z1 * p.sc1 + z2 * p.sc2 + row * p.ldc + col;
-        float v = p.alpha * s;
-        if (p.beta != 0.f) v += p.beta * C[p.cin_delta];
-        if (p.bias) v += p.bias[col];
+        float v = epi_value(p.alpha, s, p.beta, C + p.cin_delta, p.bias ? p.bias[col] : 0.f);
         if (p.epi == 1) { if (p.aux) C[p.aux - p.C] = v; v = silu_f(v); }
         else if (p.epi == 2) v *= silu_grad_f(C[p.aux - p.C]);
         *C = v;
@@ -610,9 +614,7 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(const KParams p, int B
         for (int j = 0; j < 4; ++j) {
             const int64_t col = col0 + j;
             if (col < p.N) {
-                float o = p.alpha * v[j];
-                if (p.beta != 0.f) o += p.beta * C[col + p.cin_delta];
-                if (p.bias) o += p.bias[col];
+                float o = epi_value(p.alpha, v[j], p.beta, C + col + p.cin_delta, p.bias ? p.bias[col] : 0.f);
                 if (p.epi == 1) { if (p.aux) C[col + (p.aux - p.C)] = o; o = silu_f(o); }
                 else if (p.epi == 2) o *= silu_grad_f(C[col + (p.aux - p.C)]);
                 C[col] = o;

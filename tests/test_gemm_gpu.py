@@ -188,7 +188,8 @@ def test_in_kernel_slice_combine_equals_the_reduce_pass(cuda, mode, M, N, K, nb,
 
     want = run(False)
     for _ in range(3):
-        assert torch.equal(run(True), want)
+        got = run(True)
+        assert torch.equal(got, want), f"max |diff| {(got - want).abs().max().item()} at {int((got != want).sum())} elements"
     assert int(ops.counters(ops.workspace(cuda)).abs().sum().item()) == 0
     ref = 0.7 * ((a.transpose(1, 2) if ta else a).double() @ (b.transpose(1, 2) if tb else b).double()) + 0.3 * res.double() + bias.double()
     assert (want.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
