@@ -25,7 +25,7 @@ constexpr int D = 128, BQ = 128, BKEY = 32, TILE = BKEY * D;   // floats per K o
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ v, float* __restrict__ out, int64_t T,
                                                             int64_t row_stride, int64_t batch_stride, int64_t out_row_stride,
-                                                            int64_t out_batch_stride, float scale) {
+                                                            int64_t out_batch_stride, float scale, float* __restrict__ lse) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE];   // 2 stages x (K tile, V tile) = 64 KB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
@@ -147,6 +147,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();                                      // ... everybody's has, and every wave is done reading this stage
         cur ^= 1;
     }
+    // grad mode: the backward re-forms P = exp(s - lse) tile by tile from this one number per query row
+    if (lse != nullptr && h == 0 && q0 + i < T) lse[(b * gridDim.y + head) * T + q0 + i] = m_run + __logf(l_run);
     // normalise and store: O[query (e, h)][4 i + t]
     const float inv = 1.f / l_run;
     float* ob = out + b * out_batch_stride + head * D;
@@ -157,6 +159,198 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int64_t row = q0 + r;
         if (row < T)
             *reinterpret_cast<float4*>(ob + row * out_row_stride + 4 * i) = make_float4(o[0][e] * w, o[1][e] * w, o[2][e] * w, o[3][e] * w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward of the fused attention (grad-mode windows of Loop A, reference lcasr/lib.py:550,579), recomputing the probabilities tile
+// by tile from (Q, K, lse) instead of reading a materialised [T, T] matrix.  Deterministic: no float atomics —
+//   KEY_OWNER = false: one workgroup owns 128 QUERY rows, walks all key tiles:  dQ = scale * sum_j dS_ij K_j          (3 products)
+//                      and writes delta_i = sum_d dO_i O_i for the second kernel;
+//   KEY_OWNER = true : one workgroup owns 128 KEY rows, walks all query tiles:  dV = sum_i P_ij dO_i,  dK = scale * sum_i dS_ij Q_i
+//                                                                                                                       (4 products)
+// with dS = P o (dP - delta), dP = dO V^T, P = exp(scale * Q K^T - lse).  Both are the forward kernel's structure: the owner's rows
+// live in registers as MFMA B operands, the other side arrives in 32-row tiles by direct-to-LDS loads (two tensors, two stages,
+// 64 KB), s / dp come out in the C layout "lane = owner row, register = tile row", and P^T / dS^T in that layout ARE the A operands
+// of the accumulating products (no transpose, no LDS round trip).  Both staged tensors are stored with the source-address swizzle
+// slot ^ (row & 15): conflict-free for the A-operand reads (lane = row) and for the B-operand reads (lane = 16-B column slot).
+template <bool KEY_OWNER>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                            const float* __restrict__ o, const float* __restrict__ dout,
+                                                            const float* __restrict__ lse, float* __restrict__ delta,
+                                                            float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                            int64_t T, int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
+                                                            int64_t o_batch_stride, int64_t g_row_stride, int64_t g_batch_stride, float scale) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE];
+    __shared__ __attribute__((aligned(16))) float rowstat[2][2][BKEY];     // [stage][lse | delta][tile row]   (KEY_OWNER only)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t b = blockIdx.z, head = blockIdx.y, H = gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.x * BQ + wave * 32;                 // first owner row of this wave
+    const float* qb = q + b * batch_stride + head * D;
+    const float* kb = k + b * batch_stride + head * D;
+    const float* vb = v + b * batch_stride + head * D;
+    const float* ob = o + b * o_batch_stride + head * D;
+    const float* gb = dout + b * o_batch_stride + head * D;
+    const float* lse_b = lse + (b * H + head) * T;
+    float* delta_b = delta + (b * H + head) * T;
+
+    // owner rows in registers (B-operand layout: lane (i, h) holds row i, d = 8c + 4h .. +3)
+    const int64_t orow = (r0 + i < T) ? r0 + i : T - 1;
+    float f1[16][4], f2[16][4];              // query owner: scale * Q, dO          key owner: scale * K, V
+    float my_lse = 0.f, my_delta = 0.f;
+    {
+        const float* s1 = KEY_OWNER ? kb : qb;
+        const float* s2 = KEY_OWNER ? vb : gb;
+        const int64_t st2 = KEY_OWNER ? row_stride : o_row_stride;
+        float dsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float4 a = *reinterpret_cast<const float4*>(s1 + orow * row_stride + 8 * c + 4 * h);
+            const float4 g = *reinterpret_cast<const float4*>(s2 + orow * st2 + 8 * c + 4 * h);
+            f1[c][0] = a.x * scale; f1[c][1] = a.y * scale; f1[c][2] = a.z * scale; f1[c][3] = a.w * scale;
+            f2[c][0] = g.x; f2[c][1] = g.y; f2[c][2] = g.z; f2[c][3] = g.w;
+            if (!KEY_OWNER) {
+                const float4 oo = *reinterpret_cast<const float4*>(ob + orow * o_row_stride + 8 * c + 4 * h);
+                dsum += (g.x * oo.x + g.y * oo.y) + (g.z * oo.z + g.w * oo.w);
+            }
+        }
+        if (!KEY_OWNER) {
+            my_delta = dsum + __shfl_xor(dsum, 32, 64);
+            my_lse = lse_b[orow];
+            if (h == 0 && r0 + i < T) delta_b[r0 + i] = my_delta;
+        }
+    }
+
+    // tiles of the other side: query owner walks (K, V); key owner walks (Q, dO)
+    const float* t1b = KEY_OWNER ? qb : kb;
+    const float* t2b = KEY_OWNER ? gb : vb;
+    const int64_t t1s = row_stride, t2s = KEY_OWNER ? o_row_stride : row_stride;
+    const float* src1[4];
+    const float* src2[4];
+    const int prow_in = lane >> 5, pslot = lane & 31;
+    auto set_src = [&](int64_t row0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (wave * 4 + j) * 2 + prow_in;
+            int64_t row = row0 + r;
+            row = row < T ? row : T - 1;
+            src1[j] = t1b + row * t1s + 4 * (pslot ^ (r & 15));
+            src2[j] = t2b + row * t2s + 4 * (pslot ^ (r & 15));
+        }
+    };
+    auto glds16 = [&](const float* src, float* dst) {
+        unsigned keep;
+        const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)dst);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+    };
+    auto issue = [&](int stage, int64_t row0) {
+        float* st = smem + stage * 2 * TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(src1[j], st + (wave * 4 + j) * 256);
+            glds16(src2[j], st + TILE + (wave * 4 + j) * 256);
+        }
+        if (KEY_OWNER && threadIdx.x < 2 * BKEY) {       // lse / delta of the tile's 32 query rows
+            const int which = threadIdx.x >> 5, r = threadIdx.x & 31;
+            const int64_t row = row0 + r < T ? row0 + r : T - 1;
+            rowstat[stage][which][r] = which == 0 ? lse_b[row] : delta_b[row];
+        }
+    };
+
+    f32x16 acc1[4], acc2[4];                 // query owner: acc1 = dQ          key owner: acc1 = dK, acc2 = dV
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc1[t][e] = 0.f; acc2[t][e] = 0.f; }
+
+    const int64_t ntiles = (T + BKEY - 1) / BKEY;
+    set_src(0);
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int64_t kt = 0; kt < ntiles; ++kt) {
+        const float* t1 = smem + cur * 2 * TILE;
+        const float* t2 = t1 + TILE;
+        if (kt + 1 < ntiles) {
+            set_src((kt + 1) * BKEY);
+            issue(cur ^ 1, (kt + 1) * BKEY);
+        }
+        // s[tile row][owner row] and dp[tile row][owner row]: A = tile (rows from LDS), B = owner registers
+        f32x16 s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float4 a1 = *reinterpret_cast<const float4*>(&t1[i * D + 4 * ((2 * c + h) ^ (i & 15))]);
+            const float4 a2 = *reinterpret_cast<const float4*>(&t2[i * D + 4 * ((2 * c + h) ^ (i & 15))]);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, f1[c][0], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, f2[c][0], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, f1[c][1], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, f2[c][1], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, f1[c][2], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.z, f2[c][2], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, f1[c][3], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.w, f2[c][3], dp, 0, 0, 0);
+        }
+        // register e of lane (owner i, half h) = tile row (e & 3) + 8 * (e >> 2) + 4 * h.  p = exp(s - lse[query]), ds = p * (dp - delta[query]);
+        // tile rows past T contribute nothing (their loads were clamped to a valid row).
+        const int64_t row_base = kt * BKEY + 4 * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float l4[4], d4[4];
+            if (KEY_OWNER) {
+                const float4 lv = *reinterpret_cast<const float4*>(&rowstat[cur][0][8 * c + 4 * h]);
+                const float4 dv4 = *reinterpret_cast<const float4*>(&rowstat[cur][1][8 * c + 4 * h]);
+                l4[0] = lv.x; l4[1] = lv.y; l4[2] = lv.z; l4[3] = lv.w;
+                d4[0] = dv4.x; d4[1] = dv4.y; d4[2] = dv4.z; d4[3] = dv4.w;
+            }
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int e = 4 * c + qq;
+                const bool live = row_base + 8 * c + qq < T;
+                const float pe = live ? __expf(s[e] - (KEY_OWNER ? l4[qq] : my_lse)) : 0.f;
+                s[e] = pe;                                                        // P^T (query owner: P^T[key][query]; key owner: P[query][key])
+                dp[e] = pe * (dp[e] - (KEY_OWNER ? d4[qq] : my_delta));          // dS in the same layout
+            }
+        }
+        // accumulate: A = s / dp straight from the accumulator registers (k = tile row 8c + 4h + qq), B = tile[row][4i + t]
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int r = 8 * c + 4 * h + qq;
+                const float4 b1 = *reinterpret_cast<const float4*>(t1 + r * D + 4 * (i ^ (r & 15)));
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[4 * c + qq], b1.x, acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[4 * c + qq], b1.y, acc1[1], 0, 0, 0);
+                acc1[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[4 * c + qq], b1.z, acc1[2], 0, 0, 0);
+                acc1[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[4 * c + qq], b1.w, acc1[3], 0, 0, 0);
+                if (KEY_OWNER) {
+                    const float4 b2 = *reinterpret_cast<const float4*>(t2 + r * D + 4 * (i ^ (r & 15)));
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[4 * c + qq], b2.x, acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[4 * c + qq], b2.y, acc2[1], 0, 0, 0);
+                    acc2[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[4 * c + qq], b2.z, acc2[2], 0, 0, 0);
+                    acc2[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[4 * c + qq], b2.w, acc2[3], 0, 0, 0);
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    // store: rows = owner rows (register, half), columns 4i + t.  The tile-side operand of acc1 (K or Q) was NOT pre-scaled: apply scale.
+    float* out1 = (KEY_OWNER ? dk : dq) + b * g_batch_stride + head * D;
+    float* out2 = dv + b * g_batch_stride + head * D;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int64_t row = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < T) {
+            *reinterpret_cast<float4*>(out1 + row * g_row_stride + 4 * i) =
+                make_float4(acc1[0][e] * scale, acc1[1][e] * scale, acc1[2][e] * scale, acc1[3][e] * scale);
+            if (KEY_OWNER)
+                *reinterpret_cast<float4*>(out2 + row * g_row_stride + 4 * i) = make_float4(acc2[0][e], acc2[1][e], acc2[2][e], acc2[3][e]);
+        }
     }
 }
 }  // namespace
@@ -174,6 +368,44 @@ extern "C" int dyn_attention_fwd(const float* q, const float* k, const float* v,
     if (B == 0 || T == 0) return DYN_OK;
     dim3 grid((unsigned)dyn::cdiv(T, BQ), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, row_stride, batch_stride,
-                       out_row_stride, out_batch_stride, scale);
+                       out_row_stride, out_batch_stride, scale, (float*)nullptr);
     return dyn::check_launch("dyn_attention_fwd");
+}
+
+extern "C" int dyn_attention_fwd_lse(const float* q, const float* k, const float* v, float* out, float* lse, int64_t B, int64_t T,
+                                     int64_t H, int64_t head_dim, int64_t row_stride, int64_t batch_stride, int64_t out_row_stride,
+                                     int64_t out_batch_stride, float scale, void* stream) {
+    DYN_REQUIRE(q && k && v && out && lse && B >= 0 && T >= 0 && H > 0, DYN_E_ARG, "dyn_attention_fwd_lse: bad arguments");
+    DYN_REQUIRE(head_dim == D, DYN_E_UNSUPPORTED, "dyn_attention_fwd_lse: head_dim %lld (the fused kernel is built for 128)", (long long)head_dim);
+    DYN_REQUIRE(row_stride % 4 == 0 && batch_stride % 4 == 0 && out_row_stride % 4 == 0 && out_batch_stride % 4 == 0 &&
+                    ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0, DYN_E_ARG,
+                "dyn_attention_fwd_lse: q / k / v / out must be 16-byte aligned with strides that are multiples of 4 floats");
+    if (B == 0 || T == 0) return DYN_OK;
+    dim3 grid((unsigned)dyn::cdiv(T, BQ), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, row_stride, batch_stride,
+                       out_row_stride, out_batch_stride, scale, lse);
+    return dyn::check_launch("dyn_attention_fwd_lse");
+}
+
+extern "C" int dyn_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout, const float* lse,
+                                 float* delta, float* dq, float* dk, float* dv, int64_t B, int64_t T, int64_t H, int64_t head_dim,
+                                 int64_t row_stride, int64_t batch_stride, int64_t out_row_stride, int64_t out_batch_stride,
+                                 int64_t grad_row_stride, int64_t grad_batch_stride, float scale, void* stream) {
+    DYN_REQUIRE(q && k && v && out && dout && lse && delta && dq && dk && dv && B >= 0 && T >= 0 && H > 0, DYN_E_ARG,
+                "dyn_attention_bwd: bad arguments");
+    DYN_REQUIRE(head_dim == D, DYN_E_UNSUPPORTED, "dyn_attention_bwd: head_dim %lld (the fused kernel is built for 128)", (long long)head_dim);
+    DYN_REQUIRE(row_stride % 4 == 0 && batch_stride % 4 == 0 && out_row_stride % 4 == 0 && out_batch_stride % 4 == 0 &&
+                    grad_row_stride % 4 == 0 && grad_batch_stride % 4 == 0 &&
+                    ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out) | ((uintptr_t)dout) | ((uintptr_t)dq) |
+                      ((uintptr_t)dk) | ((uintptr_t)dv)) & 15) == 0, DYN_E_ARG,
+                "dyn_attention_bwd: tensors must be 16-byte aligned with strides that are multiples of 4 floats");
+    if (B == 0 || T == 0) return DYN_OK;
+    dim3 grid((unsigned)dyn::cdiv(T, BQ), (unsigned)H, (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    // query owners first: they also produce delta, which the key owners read
+    hipLaunchKernelGGL((attention_bwd_kernel<false>), grid, dim3(256), 0, st, q, k, v, out, dout, lse, delta, dq, dk, dv, T, row_stride,
+                       batch_stride, out_row_stride, out_batch_stride, grad_row_stride, grad_batch_stride, scale);
+    hipLaunchKernelGGL((attention_bwd_kernel<true>), grid, dim3(256), 0, st, q, k, v, out, dout, lse, delta, dq, dk, dv, T, row_stride,
+                       batch_stride, out_row_stride, out_batch_stride, grad_row_stride, grad_batch_stride, scale);
+    return dyn::check_launch("dyn_attention_bwd");
 }

@@ -152,6 +152,9 @@ class SCConformerXL:
         self.grouped_wgrad = os.environ.get("DYN_GROUPED_WGRAD", "1") != "0"  # block weight gradients deferred to ONE grouped launch
                                                                               # at the end of the backward (+ bias column sums)
         self._wq = None
+        # grad-mode attention without the [B, H, T', T'] score matrix (forward keeps one log-sum-exp per row, the backward re-forms P
+        # tile by tile: 7 products instead of 4): "0" never, "1" always, otherwise from T' >= this many frames
+        self.fused_attention_grad = os.environ.get("DYN_FUSED_ATTN_GRAD", "4096")
         self.training = False
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -272,7 +275,7 @@ class SCConformerXL:
             self._ctx_static = False
             return self._forward_eager(x)
         G = self._graphs
-        key = (tuple(x.shape), torch.is_grad_enabled(), self.fused_convmod, self.fused_attention, self.fused_silu)
+        key = (tuple(x.shape), torch.is_grad_enabled(), self.fused_convmod, self.fused_attention, self.fused_silu, str(self.fused_attention_grad))
         ent = G["fwd"].get(key)
         if ent is None:
             G["seen"][key] = G["seen"].get(key, 0) + 1
@@ -386,6 +389,11 @@ class SCConformerXL:
         qkv = ops.linear(n, P[p + ".qkv.weight"], P[p + ".qkv.bias"])
         cos, sin = self._rotary(T)
         ops.rotary(qkv, cos, sin, B, T, 2 * H, D, 3 * HD)
+        if lc is not None and D == 128 and self._fused_grad_attention(T):
+            O, lse = ops.attention_fwd(qkv, B, T, H, D, 1.0 / math.sqrt(D), want_lse=True)
+            out = ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], beta=1.0, residual=h)
+            lc["attn"] = (h, mean, rstd, n, qkv, lse, O)
+            return out
         if lc is None and self.fused_attention and D == 128 and B * H * ((T + 127) // 128) >= 320:
             # no-grad pass with enough (batch, head, query-block) workgroups to fill the chip: fused kernel, scores stay on chip
             O = ops.attention_fwd(qkv, B, T, H, D, 1.0 / math.sqrt(D))
@@ -404,6 +412,10 @@ class SCConformerXL:
         if lc is not None:
             lc["attn"] = (h, mean, rstd, n, qkv, S, O)
         return out
+
+    def _fused_grad_attention(self, T):
+        mode = str(self.fused_attention_grad)
+        return mode == "1" or (mode != "0" and T >= int(mode))
 
     def _cnorm_fwd(self, c, p):
         cfg, P = self.config, self.P
@@ -559,6 +571,12 @@ class SCConformerXL:
         B, T, _ = h.shape
         scale = 1.0 / math.sqrt(D)
         dO = self._lin_bwd(dh, O, p + ".out.weight", p + ".out.bias")
+        if S.dim() == 3:        # fused forward kept lse [B, H, T] instead of the probabilities
+            dqkv = ops.attention_bwd(qkv, O, dO, S, B, T, H, D, scale)
+            cos, sin = self._rotary(T)
+            ops.rotary(dqkv, cos, sin, B, T, 2 * H, D, 3 * HD, inverse=True)
+            dn = self._lin_bwd(dqkv, n, p + ".qkv.weight", p + ".qkv.bias")
+            return self._res_norm_bwd(h, p + ".norm.weight", p + ".norm.bias", mean, rstd, dn, dh)
         dqkv = torch.empty_like(qkv)
         sS, sQ, sO = (H * T * T, T * T), (T * 3 * HD, D), (T * HD, D)
         # dV = P^T dO

@@ -367,17 +367,38 @@ def specaug_timemask(x, t0, width, value=0.0):
     return x
 
 
-def attention_fwd(qkv, B, T, H, D, scale, out=None):
-    """Fused no-grad attention on the packed [B, T, 3 * H * D] QKV activation (q | k | v, head h at +h * D) -> [B, T, H * D]."""
+def attention_fwd(qkv, B, T, H, D, scale, out=None, want_lse=False):
+    """Fused attention on the packed [B, T, 3 * H * D] QKV activation (q | k | v, head h at +h * D) -> [B, T, H * D];
+    with `want_lse` (grad mode) returns (out, lse [B, H, T]) for attention_bwd."""
     _cc(qkv, "attention.qkv")
     HD = H * D
     out = torch.empty(B, T, HD, device=qkv.device, dtype=F32) if out is None else out
     if GEMM_PROFILE is not None:
         GEMM_PROFILE["attn_flops"] = GEMM_PROFILE.get("attn_flops", 0.0) + 4.0 * B * H * T * T * D   # matrix-core work outside dyn_gemm_f32
     base = qkv.data_ptr()
+    if want_lse:
+        lse = torch.empty(B, H, T, device=qkv.device, dtype=F32)
+        check(_L().dyn_attention_fwd_lse(base, base + 4 * HD, base + 8 * HD, out.data_ptr(), lse.data_ptr(), B, T, H, D, 3 * HD, T * 3 * HD,
+                                         HD, T * HD, scale, _stream()), "dyn_attention_fwd_lse")
+        return out, lse
     check(_L().dyn_attention_fwd(base, base + 4 * HD, base + 8 * HD, out.data_ptr(), B, T, H, D, 3 * HD, T * 3 * HD, HD, T * HD, scale,
                                  _stream()), "dyn_attention_fwd")
     return out
+
+
+def attention_bwd(qkv, out, dout, lse, B, T, H, D, scale, dqkv=None):
+    """Backward of attention_fwd: (packed qkv, out, dout [B, T, H * D], lse [B, H, T]) -> packed dqkv [B, T, 3 * H * D]."""
+    _cc(qkv, "attention_bwd.qkv"); _cc(out, "attention_bwd.out"); _cc(dout, "attention_bwd.dout"); _cc(lse, "attention_bwd.lse")
+    HD = H * D
+    dqkv = torch.empty_like(qkv) if dqkv is None else _cc(dqkv, "attention_bwd.dqkv")
+    delta = torch.empty(B, H, T, device=qkv.device, dtype=F32)
+    if GEMM_PROFILE is not None:
+        GEMM_PROFILE["attn_flops"] = GEMM_PROFILE.get("attn_flops", 0.0) + 14.0 * B * H * T * T * D   # 3 + 4 products (P is re-formed twice)
+    base, g = qkv.data_ptr(), dqkv.data_ptr()
+    check(_L().dyn_attention_bwd(base, base + 4 * HD, base + 8 * HD, out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                 g, g + 4 * HD, g + 8 * HD, B, T, H, D, 3 * HD, T * 3 * HD, HD, T * HD, 3 * HD, T * 3 * HD, scale, _stream()),
+          "dyn_attention_bwd")
+    return dqkv
 
 
 # ----------------------------------------------------------------------------------------------- norms

@@ -241,6 +241,20 @@ int dyn_cutout(float* x, int64_t F, int64_t T, const int32_t* rects, int64_t n_r
 int dyn_attention_fwd(const float* q, const float* k, const float* v, float* out, int64_t B, int64_t T, int64_t H,
                       int64_t head_dim, int64_t row_stride, int64_t batch_stride, int64_t out_row_stride,
                       int64_t out_batch_stride, float scale, void* stream);
+/* Grad-mode variant (the B = 2 forward of every adapt step, reference lcasr/lib.py:550): same kernel, additionally writes
+ * lse [B, H, T] = log sum_j exp(scale * q_i k_j) per query row — all the backward needs to re-form the probabilities. */
+int dyn_attention_fwd_lse(const float* q, const float* k, const float* v, float* out, float* lse, int64_t B, int64_t T, int64_t H,
+                          int64_t head_dim, int64_t row_stride, int64_t batch_stride, int64_t out_row_stride,
+                          int64_t out_batch_stride, float scale, void* stream);
+/* Backward of the fused attention (`loss.backward()`, reference lcasr/lib.py:579, through softmax(q k^T) v): dq / dk / dv from
+ * (q, k, v, out, dout, lse), recomputing P tile by tile from LDS-staged tiles — no [T, T] matrix is read or written.
+ * Deterministic (no float atomics): query-owner workgroups produce dq and delta [B, H, T] (scratch: rowsum(dout * out)), then
+ * key-owner workgroups produce dk and dv.  dout / out share (out_row_stride, out_batch_stride); dq / dk / dv share
+ * (grad_row_stride, grad_batch_stride) — e.g. the three thirds of a packed [B, T, 3 * H * 128] gradient buffer. */
+int dyn_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout, const float* lse,
+                      float* delta, float* dq, float* dk, float* dv, int64_t B, int64_t T, int64_t H, int64_t head_dim,
+                      int64_t row_stride, int64_t batch_stride, int64_t out_row_stride, int64_t out_batch_stride,
+                      int64_t grad_row_stride, int64_t grad_batch_stride, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CTC.  dyn_ctc_greedy replaces GreedyCTCDecoder on a CPU copy of the posteriors (reference lcasr/lib.py:498,

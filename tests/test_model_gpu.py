@@ -47,6 +47,26 @@ def test_forward_backward_parity(cuda, cfg_over, T):
     print("worst relative grad error", worst)
 
 
+def test_fused_grad_attention_forward_backward_parity(cuda):
+    """The whole model with the streaming grad-mode attention (no [B, H, T', T'] scores; forward keeps lse, backward re-forms P):
+    log-probs and every parameter gradient vs the CPU oracle, and the n_active backward shortcut on top of it."""
+    ref, hip = _pair(cuda, SMALL, vocab=128)
+    hip.fused_attention_grad = "1"
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 80, 300, generator=g)
+    out_ref = ref(audio_signal=x)['final_posteriors']
+    out = hip(audio_signal=x.to(cuda))['final_posteriors']
+    assert (out.cpu() - out_ref).abs().max().item() < 2e-4 and torch.equal(out.cpu().argmax(-1), out_ref.argmax(-1))
+    gp = torch.zeros(out_ref.shape)
+    gp[0] = torch.randn(out_ref.shape[1:], generator=g) / out_ref[0].numel()
+    out_ref.backward(gp)
+    hip.zero_grad()
+    hip.backward(gp[:1].contiguous().to(cuda), n_active=1)
+    for (n, p), gh in zip(ref.named_parameters(), hip.grads()):
+        rel = (gh.cpu() - p.grad).abs().max().item() / (p.grad.abs().max().item() + 1e-12)
+        assert rel < 2e-3, f"grad {n}: rel err {rel}"
+
+
 def test_backward_active_subset_matches_full(cuda):
     """Skipping the clean copy (zero gradient) must give the same parameter gradients as the full backward."""
     ref, hip = _pair(cuda, SMALL, vocab=128)
