@@ -25,7 +25,7 @@ __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { retur
 
 // ids[row] = argmax_c x[row, c]   (first maximum wins, as torch.argmax on CPU)
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int32_t* __restrict__ ids,
-                                                           int64_t rows, int C, int64_t ld) {
+                                                           int64_t rows, int C, int64_t ld, float* __restrict__ vals) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
         const float* xr = x + row * ld;
@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
             const int oi = __shfl_xor(bi, o, 64);
             if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
         }
-        if (lane == 0) ids[row] = bi == 0x7fffffff ? 0 : bi;
+        if (lane == 0) {
+            ids[row] = bi == 0x7fffffff ? 0 : bi;
+            if (vals) vals[row] = bv;
+        }
     }
 }
 
@@ -373,10 +376,19 @@ extern "C" int dyn_ctc_greedy(const float* log_probs, int64_t B, int64_t T, int6
     if (T > 0) {
         int64_t g = dyn::cdiv(B * T, 4);
         if (g > 8192) g = 8192;
-        hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, log_probs, argmax_ids, B * T, (int)C, ld);
+        hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, log_probs, argmax_ids, B * T, (int)C, ld, (float*)nullptr);
     }
     hipLaunchKernelGGL(ctc_collapse_kernel, dim3((unsigned)B), dim3(1024), 0, st, argmax_ids, out_ids, out_len, T, T, (int)blank);
     return dyn::check_launch("dyn_ctc_greedy");
+}
+
+extern "C" int dyn_argmax_rows(const float* x, int64_t rows, int64_t C, int64_t ld, int32_t* ids, float* vals, void* stream) {
+    DYN_REQUIRE(x && ids && rows >= 0 && C > 0 && ld >= C, DYN_E_ARG, "dyn_argmax_rows: bad arguments");
+    if (rows == 0) return DYN_OK;
+    int64_t g = dyn::cdiv(rows, 4);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, ids, rows, (int)C, ld, vals);
+    return dyn::check_launch("dyn_argmax_rows");
 }
 
 extern "C" int64_t dyn_ctc_loss_workspace_bytes(int64_t T, int64_t B, int64_t S_max) {

@@ -791,8 +791,11 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
     kp.epi = d->epilogue; kp.aux = d->aux;
     // in-kernel combine of K slices: needs one zeroed arrival counter per partial tile
     const int64_t n_ptiles = pl.splits > 1 ? tiles_m * tiles_n * batch : pl.tail_items;
-    static const bool allow_ticket = [] { const char* e = getenv("DYN_GEMM_TICKET"); return !e || atoi(e) != 0; }();
-    kp.counters = (allow_ticket && d->counters && n_ptiles > 0 && n_ptiles <= d->n_counters) ? d->counters : nullptr;
+    // The caller opts in by handing over counters.  The host wrapper does so only under DYN_GEMM_TICKET=1: measured on the 1 h job
+    // (3 chains, one box, alternating runs) 577 audio-s/s with the in-kernel combine against 774 with the separate reduce pass —
+    // the device-scope release / acquire fences write back and invalidate the XCD's whole L2 (buffer_wbl2 / buffer_inv sc1) under
+    // every other kernel that shares it.  Kept because it is bit-identical and needs no second launch when a GEMM runs alone.
+    kp.counters = (d->counters && n_ptiles > 0 && n_ptiles <= d->n_counters) ? d->counters : nullptr;
     kp.colsum = nullptr; kp.colsum_beta = 0.f; kp.first_item = 0;
     const int64_t nblocks = pl.full_items + pl.tail_items * pl.tail_f;
     DYN_REQUIRE(nblocks < (1ll << 31) && tiles_m * tiles_n < (1ll << 31), DYN_E_ARG, "dyn_gemm_f32: grid too large (%lld workgroups)",

@@ -101,7 +101,9 @@ class _Group:
 
 
 class SCConformerXL:
-    def __init__(self, config=None, vocab_size=128, device="cuda:0"):
+    def __init__(self, config=None, vocab_size=128, device="cuda:0", extra_spec=None):
+        """`extra_spec`: [(name, shape)] of further parameters placed in the SAME flat buffers (the enc-dec model appends its
+        decoder there, so snapshot / restore / optimiser step stay single operations)."""
         self.config = make_config(**(config or {}))
         cfg = self.config
         if cfg["conv_norm"] not in ("rms_norm", "layer_norm", "batch_renorm"):
@@ -112,7 +114,7 @@ class SCConformerXL:
         if self.device.type != "cuda":
             raise ops.DynError("SCConformerXL runs only on the HIP path (device must be cuda)")
         self.num_classes = vocab_size + 1
-        self.spec = param_spec(cfg, self.num_classes)
+        self.spec = param_spec(cfg, self.num_classes) + list(extra_spec or [])
         off, self._slots = 0, {}
         for name, shape in self.spec:
             n = math.prod(shape)
@@ -354,6 +356,7 @@ class SCConformerXL:
                 if save:
                     ctx["sc"].append((h, mean, rstd, n, z))
                 h = h2
+        self._hidden = h      # encoder states before the CTC head (the enc-dec model's cross-attention reads them)
         n, mean, rstd = ops.layernorm(h, P["decoder.norm.weight"], P["decoder.norm.bias"], cfg["norm_eps"])
         z = ops.linear(n, P["decoder.ff.weight"], P["decoder.ff.bias"])
         logp = ops.log_softmax(z, out=z)
@@ -454,23 +457,26 @@ class SCConformerXL:
         return out
 
     # ------------------------------------------------------------------ backward
-    def backward(self, grad_posteriors, n_active=None, input_grad=False, param_grads=True):
+    def backward(self, grad_posteriors, n_active=None, input_grad=False, param_grads=True, grad_hidden=None):
         """Gradient of a scalar loss w.r.t. every parameter, given dL/d(final_posteriors) [B, T', V+1].
         Accumulates into `flat_grads` (call zero_grad() first, as `optimizer.zero_grad()` at reference lib.py:578).
         `n_active` = nb: only the first nb samples of the batch carry a non-zero gradient (the dynamic-eval loss uses
         the augmented copies only, reference lib.py:570-575), so the backward runs on those samples; the skipped
         samples would contribute exact zeros to every gradient.
         `input_grad=True` also returns dL/d(audio_signal) [B, F, T]; `param_grads=False` skips every weight-gradient
-        product (the entropy-gradient input perturbation, reference lib.py:96, needs only the input gradient)."""
+        product (the entropy-gradient input perturbation, reference lib.py:96, needs only the input gradient).
+        `grad_hidden` [nb, T', d]: an additional gradient w.r.t. the encoder states `_hidden` (enc-dec cross-attention)."""
         self._skip_wgrad = not param_grads
+        self._grad_hidden = grad_hidden
         try:
             with ops.use_workspace(self._scratch()):
-                if self._ctx_static and self.use_graphs and not input_grad and param_grads and self._ctx is not None:
+                if self._ctx_static and self.use_graphs and not input_grad and param_grads and self._ctx is not None and grad_hidden is None:
                     return self._backward_graphed(grad_posteriors, n_active)
                 return self._backward(grad_posteriors, n_active, input_grad)
         finally:
             self._skip_wgrad = False
             self._wq = None
+            self._grad_hidden = None
 
     def _backward_graphed(self, grad_posteriors, n_active):
         G = self._graphs
@@ -524,6 +530,8 @@ class SCConformerXL:
         dh = torch.empty_like(h)
         ops.layernorm_bwd(h, P["decoder.norm.weight"], mean, rstd, dn, dh, G["decoder.norm.weight"], G["decoder.norm.bias"],
                           dx_beta=0.0)
+        if getattr(self, "_grad_hidden", None) is not None:
+            ops.axpby(self._grad_hidden.contiguous(), dh, a=1.0, b=1.0)
         nl = cfg["n_layers"]
         for l in reversed(range(nl)):
             if cfg["self_conditioning"] and l != nl - 1:

@@ -89,8 +89,11 @@ def workspace(device=None):
     return ws
 
 
+import os as _os
+
 _COUNTERS = {}
 N_COUNTERS = 16384
+TICKET_DEFAULT = _os.environ.get("DYN_GEMM_TICKET", "0") == "1"
 
 
 def counters(ws):
@@ -107,7 +110,7 @@ def counters(ws):
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
          nb1=1, nb2=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, split_k=0, force=None, c_in=None,
-         epilogue=0, aux=None, ticket=True):
+         epilogue=0, aux=None, ticket=None):
     """Raw strided batched GEMM (see dyn_gemm_desc). Offsets are in elements from each tensor's data_ptr.
     `force=(tile_m, tile_n, tail_slices)` pins the kernel configuration (autotuner / tests).
     `epilogue`: 0 none, EPI_SILU (C = silu(v), aux = v if given), EPI_SILU_GRAD (C = v * silu'(aux)); aux addressed like C."""
@@ -129,7 +132,9 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha
     d.aux = (aux.data_ptr() + 4 * c_off) if aux is not None else None
     ws = workspace(c.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-    if ticket:       # in-kernel combine of K slices (False: the separate reduce pass; tests compare the two)
+    if ticket is None:
+        ticket = TICKET_DEFAULT
+    if ticket:       # in-kernel combine of K slices instead of the separate reduce pass (opt-in: DYN_GEMM_TICKET=1; see gemm_f32.hip)
         cnt = counters(ws)
         d.counters, d.n_counters = cnt.data_ptr(), cnt.numel()
     prof = GEMM_PROFILE
@@ -653,6 +658,16 @@ def ctc_greedy(log_probs, blank):
     check(_L().dyn_ctc_greedy(lp.data_ptr(), B, T, C, C, blank, arg.data_ptr(), ids.data_ptr(), n.data_ptr(), _stream()),
           "dyn_ctc_greedy")
     return ids, n
+
+
+def argmax_rows(x):
+    """x [rows, C] -> (ids int32 [rows], max values [rows]); first maximum wins."""
+    _c(x, "argmax_rows.x")
+    rows, C = x.shape
+    ids = torch.empty(rows, device=x.device, dtype=I32)
+    vals = torch.empty(rows, device=x.device, dtype=F32)
+    check(_L().dyn_argmax_rows(x.data_ptr(), rows, C, C, ids.data_ptr(), vals.data_ptr(), _stream()), "dyn_argmax_rows")
+    return ids, vals
 
 
 def ctc_loss(log_probs, targets, input_lengths, target_lengths, blank, reduction="sum", grad_scale=1.0, want_grad=True):

@@ -257,6 +257,26 @@ int dyn_attention_bwd(const float* q, const float* k, const float* v, const floa
                       int64_t grad_row_stride, int64_t grad_batch_stride, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Encoder-decoder `teacher_ce` adaptation (reference lcasr/lib.py:1228-1322 calc_loss_enc_dec, :1475-1732 enc_dec_dynamic_eval):
+ * the decoder's dense work runs on dyn_gemm_f32 and the encoder's norm / softmax kernels; these are the pieces that are new.
+ *   dyn_embedding_fwd  out[s] = table[ids[s]] (+ pos[s % pos_period])            token embedding (+ fixed positional table)
+ *   dyn_embedding_bwd  dtable[v] = beta * dtable[v] + sum_{s: ids[s] == v} dy[s]  one workgroup per vocabulary row, no atomics
+ *   dyn_causal_mask    scores[b, r, c] = -inf for c > r                            decoder self-attention (before dyn_softmax_fwd)
+ *   dyn_nll_loss       F.cross_entropy(reduction='sum', ignore_index) on log-softmax rows (lib.py:1290-1296): loss [1], the per-row
+ *                      terms, and grad = grad_scale * (exp(logp) - onehot(target)) w.r.t. the LOGITS (0 for ignored rows)
+ * ------------------------------------------------------------------------------------------------ */
+/* ids[r] = argmax_c x[r, c] (first maximum wins, as torch.argmax), vals[r] = that maximum (may be NULL): the greedy step of the
+ * autoregressive decode (`model.generate`, reference lcasr/lib.py:1128,1580) and the teacher's mean max-probability (:1601). */
+int dyn_argmax_rows(const float* x, int64_t rows, int64_t C, int64_t ld, int32_t* ids, float* vals, void* stream);
+int dyn_embedding_fwd(const int32_t* ids, const float* table, const float* pos, float* out, int64_t S, int64_t d, int64_t vocab,
+                      int64_t pos_period, void* stream);
+int dyn_embedding_bwd(const int32_t* ids, const float* dy, float* dtable, int64_t S, int64_t d, int64_t vocab, float beta,
+                      void* stream);
+int dyn_causal_mask(float* scores, int64_t nb, int64_t S, void* stream);
+int dyn_nll_loss(const float* log_probs, const int32_t* targets, float* loss, float* row_loss, float* grad, int64_t rows, int64_t C,
+                 int32_t ignore_index, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * CTC.  dyn_ctc_greedy replaces GreedyCTCDecoder on a CPU copy of the posteriors (reference lcasr/lib.py:498,
  * 559,565; run_dynamic_eval_full.py:53,100): argmax over classes (first maximum), collapse repeats, drop `blank`.
  *   log_probs [B*T rows, C] (row stride ld); argmax_ids [B*T]; out_ids [B, T] (prefix of out_len[b] valid ids).

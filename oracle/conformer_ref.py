@@ -206,7 +206,7 @@ class SCConformerXLRef(nn.Module):
             x = blk(x)
             if self.decoder.reproj is not None and i != n - 1:
                 x = x + self.decoder.reproj(torch.softmax(self.decoder.logits(x), -1))
-        return {"final_posteriors": F.log_softmax(self.decoder.logits(x), -1)}
+        return {"final_posteriors": F.log_softmax(self.decoder.logits(x), -1), "hidden": x}
 
     def print_total_params(self):
         print(f"Total params: {sum(p.numel() for p in self.parameters()) / 1e6:.2f}M")

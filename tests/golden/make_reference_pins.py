@@ -16,6 +16,7 @@ nothing but `torch`, `re`, `random` and `typing.List` in their namespace — no 
   lcasr/run_seq_eval.py:130-144  the outer stitch statements  -> stitch_outer_*
   lcasr/tedlium/run.py:25-51     open_stm + proc_stm_and_timings on a synthetic STM file -> json
   wav2vec2/soft_dtw_cuda.py:319-329  SoftDTW._euclidean_dist_func -> sqdist_*
+  lcasr/enc_dec_teacher_filters.py   add_enc_dec_teacher_filter_args defaults + should_skip_faulty_teacher_prediction decisions -> json
 """
 import argparse
 import ast
@@ -163,6 +164,41 @@ def main():
         x, y = torch.randn(B, N, D, generator=g), torch.randn(B, M, D, generator=g)
         arrays[f"sqdist_{tag}_x"], arrays[f"sqdist_{tag}_y"] = x.numpy(), y.numpy()
         arrays[f"sqdist_{tag}_d"] = ns["_euclidean_dist_func"](x, y).numpy()
+
+    # ---- enc-dec teacher filters (lcasr/enc_dec_teacher_filters.py): flag defaults and decisions on a table of cases
+    from difflib import SequenceMatcher
+    ns = ref_functions("lcasr/enc_dec_teacher_filters.py",
+                       ["add_enc_dec_teacher_filter_args", "_sequence_similarity", "_word_sequence", "_longest_consecutive_repeat",
+                        "_find_repeated_ngram_loop", "should_skip_faulty_teacher_prediction"], dict(base, SequenceMatcher=SequenceMatcher))
+    defaults = vars(ns["add_enc_dec_teacher_filter_args"](argparse.ArgumentParser()).parse_args([]))
+    meta["teacher_filter_defaults"] = defaults
+    cases = []
+    table = [
+        (dict(teacher_filter_max_length=True), list(range(40)), "a b c", 256, {}),
+        (dict(teacher_filter_max_length=True), list(range(20)), "a b c", 256, {}),
+        (dict(teacher_filter_max_length=True, teacher_min_frames_per_token=4), list(range(40)), "a b c", 256, {}),
+        (dict(teacher_filter_max_consecutive_token_repeat=True), [5, 7, 7, 7, 7, 2], "x", 512, {}),
+        (dict(teacher_filter_max_consecutive_token_repeat=True), [5, 7, 7, 7, 2], "x", 512, {}),
+        (dict(teacher_filter_max_consecutive_token_repeat=True, teacher_max_consecutive_token_repeat=1), [1, 2, 2, 3], "x", 512, {}),
+        (dict(teacher_filter_repeated_token_ngrams=True), [1, 2, 1, 2, 9], "x", 512, {}),
+        (dict(teacher_filter_repeated_token_ngrams=True), [1, 2, 3, 1, 2, 4], "x", 512, {}),
+        (dict(teacher_filter_repeated_token_ngrams=True, teacher_repeated_token_ngram_sizes=[3], teacher_repeated_token_ngram_min_repeats=3),
+         [4, 5, 6, 4, 5, 6, 4, 5, 6, 1], "x", 512, {}),
+        (dict(teacher_filter_low_confidence=True), [1, 2], "x", 512, dict(teacher_mean_max_prob=0.2, teacher_mean_entropy=1.0)),
+        (dict(teacher_filter_low_confidence=True), [1, 2], "x", 512, dict(teacher_mean_max_prob=0.9, teacher_mean_entropy=3.1)),
+        (dict(teacher_filter_low_confidence=True), [1, 2], "x", 512, dict(teacher_mean_max_prob=0.9, teacher_mean_entropy=0.4)),
+        (dict(teacher_filter_repeated_words=True), [1], "the the the the cat", 512, {}),
+        (dict(teacher_filter_repeated_words=True), [1], "the the the cat", 512, {}),
+        (dict(teacher_filter_ctc_agreement=True), [1], "hello big world again", 512, dict(ctc_text="hello world")),
+        (dict(teacher_filter_ctc_agreement=True), [1], "hello big world again", 512, dict(ctc_text="completely different words here now")),
+        (dict(), list(range(500)), "the the the the the", 16, dict(teacher_mean_max_prob=0.0)),
+        (dict(teacher_filter_max_length=True, teacher_filter_repeated_words=True), [], "", 100, {}),
+    ]
+    for flags, tokens, text, frames, extra in table:
+        a = argparse.Namespace(**dict(defaults, **flags))
+        skip, reason = ns["should_skip_faulty_teacher_prediction"](args=a, teacher_pred_tokens=tokens, teacher_pred_text=text, spec_frames=frames, **extra)
+        cases.append({"flags": flags, "tokens": tokens, "text": text, "frames": frames, "extra": extra, "skip": bool(skip), "reason": reason})
+    meta["teacher_filter_cases"] = cases
 
     np.savez_compressed(os.path.join(HERE, "reference_pins.npz"), **arrays)
     json.dump(meta, open(os.path.join(HERE, "reference_pins.json"), "w"), indent=1)

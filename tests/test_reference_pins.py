@@ -153,3 +153,17 @@ def test_device_sqdist_reproduces_the_reference(cuda, pins):
         want = arr[f"sqdist_{tag}_d"]
         got = sqdist(torch.from_numpy(arr[f"sqdist_{tag}_x"]).to(cuda), torch.from_numpy(arr[f"sqdist_{tag}_y"]).to(cuda)).cpu().numpy()
         assert got.shape == want.shape and np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), tag
+
+
+def test_teacher_filters_reproduce_the_reference_decisions(pins):
+    """enc_dec_teacher_filters: same flag defaults and, case by case, the same (skip, reason) as the reference's
+    should_skip_faulty_teacher_prediction executed unchanged."""
+    from dynamic_asr_eval_amd.enc_dec_teacher_filters import add_enc_dec_teacher_filter_args, should_skip_faulty_teacher_prediction
+    _, meta = pins
+    defaults = vars(add_enc_dec_teacher_filter_args(argparse.ArgumentParser()).parse_args([]))
+    assert defaults == meta["teacher_filter_defaults"]
+    for case in meta["teacher_filter_cases"]:
+        a = argparse.Namespace(**dict(defaults, **case["flags"]))
+        skip, reason = should_skip_faulty_teacher_prediction(args=a, teacher_pred_tokens=case["tokens"], teacher_pred_text=case["text"],
+                                                             spec_frames=case["frames"], **case["extra"])
+        assert (bool(skip), reason) == (case["skip"], case["reason"]), case
