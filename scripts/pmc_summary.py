@@ -11,7 +11,7 @@ def per_kernel(dirname, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        key = "gemm_f32_kernel" if "gemm_f32_kernel" in name else name
+        key = "gemm_f32_kernel" if ("gemm_f32_kernel" in name or "gemm_f32_grouped_kernel" in name) else name   # one family
         agg[key][0] += 1
         agg[key][1] += float(r["Counter_Value"])
     return agg
@@ -20,10 +20,10 @@ fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
 fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
 n, f = fe["gemm_f32_kernel"]
 n2, w = wr["gemm_f32_kernel"]
-res = {"kernel": "gemm_f32_kernel", "launches": n, "fetch_size_kib_per_launch": f / n, "write_size_kib_per_launch": w / n2,
+res = {"kernel": "gemm_f32_kernel + gemm_f32_grouped_kernel", "launches": n, "fetch_size_kib_per_launch": f / n, "write_size_kib_per_launch": w / n2,
        "hbm_bytes_per_launch": (2 * f / n + w / n2) * 1024,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0 "
-                 "--seconds 300 --prewarm_s 0 --no_cpu_baseline --graphs 0 --chains 1` (one chain, eager launches: per-launch traffic does not "
+                 "--seconds 300 --prewarm_s 0 --no_cpu_baseline --side_steps 0 --graphs 0 --chains 1` (one chain, eager launches: per-launch traffic does not "
                  "depend on how launches are queued); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count correction)"}
 json.dump(res, open(out, "w"), indent=1)
 print(res)
