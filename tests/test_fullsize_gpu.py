@@ -114,3 +114,44 @@ def test_fused_attention_in_the_no_grad_pass_matches_the_unfused_sequence(cuda, 
         model.fused_attention = True
     assert (a - b).abs().max().item() < 1e-4 and not torch.equal(a, b)      # different code path (not bit-identical), same numbers
     assert torch.equal(a.argmax(-1), b.argmax(-1))
+
+
+def test_config4_whole_concat_of_four_hours_at_full_size(cuda, xl):
+    """BASELINE config 4 at its real size (reference lcasr/run_whole_concat_eval.py:123-152 -> run_half_concat_eval.adapt_on_concat_only):
+    4 x 1 h of log-mel concatenated = 1 440 000 frames -> 697 windows of 16384 / 14336 (tests/golden/prepare_chunks.json, produced by
+    the reference's own prepare_chunks), one adapt step per window on the 6 x 768 / V+1 = 4096 model, adapted weights returned and
+    the model restored bit for bit; afterwards an epochs = 0 evaluation of one part with the adapted weights.  Properties only (the
+    CPU oracle would need ~1.5 h for this): window count, finite / moved / restored weights, normalised posteriors, and the adapted
+    weights actually changing the evaluation."""
+    import json, os, time
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.datasets import synthetic_spec
+    from dynamic_asr_eval_amd.harness_common import restore_params, set_params
+    from dynamic_asr_eval_amd.run_half_concat_eval import adapt_on_concat_only, concatenate_specs
+    model, tok = xl
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prepare_chunks.json")))
+    want = [c for c in gold["cases"] if c["spec_n"] == 1440000 and c["seq_len"] == 16384 and c["overlap"] == 14336][0]
+    parts = [synthetic_spec(360000, seed=40 + i) for i in range(4)]
+    concat = concatenate_specs(parts)
+    assert concat.shape[-1] == 1440000
+    _, keys = lib.prepare_chunks(concat, 16384, 14336)
+    assert len(keys) == want["n_windows"] == 697
+    before = model.flat_params.clone()
+    args = _args(seq_len=16384, awmc=False, use_graphs=True)
+    torch.cuda.synchronize(); t0 = time.time()
+    updated = adapt_on_concat_only(args, model, concat, tok, adapt_overlap=14336)
+    torch.cuda.synchronize(); dt = time.time() - t0
+    assert torch.equal(model.flat_params, before), "weights must be restored after the adapt-only pass"
+    flat_new = torch.cat([u.reshape(-1) for u in updated])
+    assert torch.isfinite(flat_new).all()
+    moved = sum(float((u - p.cpu()).abs().max()) > 0 for u, p in zip(updated, model.parameters()))
+    assert moved > 0.9 * len(updated), f"only {moved} of {len(updated)} parameter tensors moved"
+    part = parts[1][:, :, :16384 + 4 * 2048]
+    base = lib.dynamic_eval(_args(epochs=0), model, part, 16384, 14336, tok, use_tqdm=False)
+    set_params(model, updated)
+    adapted = lib.dynamic_eval(_args(epochs=0), model, part, 16384, 14336, tok, use_tqdm=False)
+    restore_params(model, before)
+    assert torch.equal(model.flat_params, before)
+    assert adapted.shape == base.shape and np.isfinite(adapted).all() and np.abs(np.exp(adapted.astype(np.float64)).sum(-1) - 1).max() < 1e-3
+    assert np.abs(adapted - base).max() > 1e-6
+    print(f"config 4: 697 adapt steps over 4 h of audio in {dt:.1f} s = {14400 / dt:.0f} audio-s/s (one chain, adapt only)")
