@@ -101,18 +101,23 @@ struct CtcDims {
 __global__ __launch_bounds__(256) void ctc_prep_kernel(const int32_t* __restrict__ targets, const int32_t* __restrict__ tlen,
                                                         int32_t* __restrict__ next_same, int32_t* __restrict__ is_first,
                                                         int64_t S_max) {
+    // the target row is staged in LDS once: the two scans below are O(S^2) reads of it (S is a few hundred labels per window;
+    // from global memory they cost 0.4 ms of pure L2 latency on the chain's critical path)
+    extern __shared__ int32_t tg_s[];
     const int64_t b = blockIdx.x;
     const int S = tlen[b];
     const int32_t* tg = targets + b * S_max;
+    for (int k = threadIdx.x; k < S; k += blockDim.x) tg_s[k] = tg[k];
+    __syncthreads();
     for (int k = threadIdx.x; k < S; k += blockDim.x) {
-        const int c = tg[k];
+        const int c = tg_s[k];
         int nx = -1;
         for (int j = k + 1; j < S; ++j)
-            if (tg[j] == c) { nx = j; break; }
+            if (tg_s[j] == c) { nx = j; break; }
         next_same[b * S_max + k] = nx;
         int first = 1;
         for (int j = 0; j < k; ++j)
-            if (tg[j] == c) { first = 0; break; }
+            if (tg_s[j] == c) { first = 0; break; }
         is_first[b * S_max + k] = first;
     }
 }
@@ -412,7 +417,7 @@ extern "C" int dyn_ctc_loss(const float* log_probs, int64_t T, int64_t B, int64_
     CtcDims d;
     d.T_max = T; d.B = B; d.C = C; d.lp_st = lp_stride_t; d.lp_sb = lp_stride_b; d.S_max = Sm; d.L_max = L; d.blank = blank;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(ctc_prep_kernel, dim3((unsigned)B), dim3(256), 0, st, targets, target_lengths, w.next_same, w.is_first, Sm);
+    hipLaunchKernelGGL(ctc_prep_kernel, dim3((unsigned)B), dim3(256), (size_t)Sm * sizeof(int32_t), st, targets, target_lengths, w.next_same, w.is_first, Sm);
     hipLaunchKernelGGL(ctc_gather_kernel, dim3((unsigned)T, (unsigned)B), dim3(256), 0, st, log_probs, targets, input_lengths,
                        target_lengths, w.slab, d);
     int threads = (int)((L + 63) / 64 * 64);
