@@ -226,19 +226,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
     const float* t1b = KEY_OWNER ? qb : kb;
     const float* t2b = KEY_OWNER ? gb : vb;
     const int64_t t1s = row_stride, t2s = KEY_OWNER ? o_row_stride : row_stride;
-    const float* src1[4];
-    const float* src2[4];
+    // source addresses are recomputed per tile from the tile's first row (a few VALU ops per 192+ MFMAs) instead of living in 16 VGPRs
     const int prow_in = lane >> 5, pslot = lane & 31;
-    auto set_src = [&](int64_t row0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = (wave * 4 + j) * 2 + prow_in;
-            int64_t row = row0 + r;
-            row = row < T ? row : T - 1;
-            src1[j] = t1b + row * t1s + 4 * (pslot ^ (r & 15));
-            src2[j] = t2b + row * t2s + 4 * (pslot ^ (r & 15));
-        }
-    };
     auto glds16 = [&](const float* src, float* dst) {
         unsigned keep;
         const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)dst);
@@ -249,8 +238,12 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
         float* st = smem + stage * 2 * TILE;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            glds16(src1[j], st + (wave * 4 + j) * 256);
-            glds16(src2[j], st + TILE + (wave * 4 + j) * 256);
+            const int r = (wave * 4 + j) * 2 + prow_in;
+            int64_t row = row0 + r;
+            row = row < T ? row : T - 1;
+            const int sw = 4 * (pslot ^ (r & 15));
+            glds16(t1b + row * t1s + sw, st + (wave * 4 + j) * 256);
+            glds16(t2b + row * t2s + sw, st + TILE + (wave * 4 + j) * 256);
         }
         if (KEY_OWNER && threadIdx.x < 2 * BKEY) {       // lse / delta of the tile's 32 query rows
             const int which = threadIdx.x >> 5, r = threadIdx.x & 31;
@@ -266,7 +259,6 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
         for (int e = 0; e < 16; ++e) { acc1[t][e] = 0.f; acc2[t][e] = 0.f; }
 
     const int64_t ntiles = (T + BKEY - 1) / BKEY;
-    set_src(0);
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -274,10 +266,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
     for (int64_t kt = 0; kt < ntiles; ++kt) {
         const float* t1 = smem + cur * 2 * TILE;
         const float* t2 = t1 + TILE;
-        if (kt + 1 < ntiles) {
-            set_src((kt + 1) * BKEY);
-            issue(cur ^ 1, (kt + 1) * BKEY);
-        }
+        if (kt + 1 < ntiles) issue(cur ^ 1, (kt + 1) * BKEY);
         // s[tile row][owner row] and dp[tile row][owner row]: A = tile (rows from LDS), B = owner registers
         f32x16 s, dp;
 #pragma unroll
