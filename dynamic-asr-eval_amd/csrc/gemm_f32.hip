@@ -531,8 +531,14 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
     }
 }
 
+// amdgpu_waves_per_eu(2, 8): without it hipcc spends the whole 512-register budget of a 4-wave workgroup on the 128x128 tile (252
+// per wave: two such waves fill a SIMD's register file and NOTHING else can be resident beside them); asked for two waves per SIMD it
+// needs 185, which leaves room for a third, lighter wave — the HBM-bound kernels of the other recording chains.
+#ifndef DYN_GEMM_WAVES_PER_EU
+#define DYN_GEMM_WAVES_PER_EU 2
+#endif
 template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS>
-__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const KParams p) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DYN_GEMM_WAVES_PER_EU, 8))) void gemm_f32_kernel(const KParams p) {
     constexpr int SA = GLDS ? BM * BK : BM * LDK, SB = GLDS ? BN * BK : BN * LDK;
     __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
     gemm_tile<TA, TB, BM, BN, VEC, GLDS, false>(p, (int64_t)blockIdx.x, smem);
