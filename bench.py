@@ -182,7 +182,16 @@ def cpu_baseline(a, hip_model, dev):
             mism += int(bad.sum())
         hyp_h.append(tok.decode(greedy_ctc_ids(torch.from_numpy(got), a.vocab)))
         hyp_o.append(tok.decode(greedy_ctc_ids(torch.from_numpy(want), a.vocab)))
-    parity = {"max_abs_dlogp": float(f"{worst:.3e}"), "argmax_equal": mism == 0, "argmax_mismatch_frames": mism, "frames": frames,
+    # the adapted transcripts of a seeded model are (nearly) empty, so the decoded-text comparison is also made on window 0 BEFORE any
+    # adaptation (epochs = 0), where the calibrated model emits a few hundred tokens
+    a0 = make_args(a); a0.epochs = 0
+    win0 = spec[:, :, :a.seq_len]
+    want0 = dynamic_eval_ref(model, win0, a.seq_len, 0, tok, MADGRAD, {'lr': a.lr}, {}, epochs=0, online=False)
+    got0 = lib.dynamic_eval(a0, hip_model, win0.contiguous().to(dev), a.seq_len, 0, tok, use_tqdm=False)
+    h0, o0 = greedy_ctc_ids(torch.from_numpy(got0), a.vocab), greedy_ctc_ids(torch.from_numpy(want0), a.vocab)
+    unadapted = {"max_abs_dlogp": float(f"{float(np.abs(got0 - want0).max()):.3e}"), "argmax_equal": bool((got0.argmax(-1) == want0.argmax(-1)).all()),
+                 "tokens": len(o0), "wer_counters_hip_vs_oracle": list(edit_counts([tok.decode(h0)], [tok.decode(o0)]))}
+    parity = {"max_abs_dlogp": float(f"{worst:.3e}"), "argmax_equal": mism == 0, "unadapted_window0": unadapted, "argmax_mismatch_frames": mism, "frames": frames,
               "largest_oracle_margin_at_a_mismatch": min_margin, "windows": n_win,
               "wer_counters_hip_vs_oracle": list(edit_counts(hyp_h, hyp_o)),
               "what": "adapted + stitched log-probs of the cpu_baseline windows: HIP path vs CPU oracle, same weights and SpecAugment masks; "

@@ -145,8 +145,8 @@ class EncDecSCConformerXL(SCConformerXL):
         return O, (Pm if save else None)
 
     def _attend_bwd(self, dO, Pm, q, k, v, dq, dk, dv, S, Tk, ldq, ldk):
-        """Gradients of _attend into the (strided) dq / dk / dv views; dk / dv are ACCUMULATED when they alias shared storage? No:
-        every view is written exactly once per call (beta = 0)."""
+        """Gradients of _attend into the (strided) dq / dk / dv views of the packed projection gradients; each view is written
+        exactly once (beta = 0)."""
         Hh, dd = self.dec["dec_heads"], self.dec["dec_d_model"]
         hd = dd // Hh
         sP = (0, S * Tk)
