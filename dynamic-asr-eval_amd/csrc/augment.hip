@@ -110,3 +110,21 @@ extern "C" int dyn_cutout(float* x, int64_t F, int64_t T, const int32_t* rects, 
                        mode == 1 ? 1 : 0);
     return dyn::check_launch("dyn_cutout");
 }
+
+
+// ---- device-side delay: one wave waits on the constant-rate (100 MHz) realtime counter.  Used by lib.dynamic_eval_many to start the
+// recording chains out of phase (identical chains started together stay phase-locked: all of them run their HBM-bound / latency-bound
+// stretches at the same time and the matrix cores idle).
+namespace {
+__global__ void sleep_kernel(long long ticks) {
+    const long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+}
+}  // namespace
+
+extern "C" int dyn_sleep_us(int64_t microseconds, void* stream) {
+    DYN_REQUIRE(microseconds >= 0 && microseconds <= 2000000, DYN_E_ARG, "dyn_sleep_us: 0 <= microseconds <= 2e6");
+    if (microseconds == 0) return DYN_OK;
+    hipLaunchKernelGGL(sleep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
+    return dyn::check_launch("dyn_sleep_us");
+}

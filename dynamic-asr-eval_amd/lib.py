@@ -478,6 +478,15 @@ def dynamic_eval_many(args, models, specs, seq_len, overlap, tokenizer, **kw):
     main = torch.cuda.current_stream(device)
     for st in streams:
         st.wait_stream(main)
+    # Identical chains started together stay phase-locked (same kernels at the same time: when all of them are in their HBM-bound or
+    # latency-bound stretches the matrix cores idle).  Chain k therefore starts `k * stagger` later, by a device-side delay on its stream.
+    import os
+    stagger_us = int(float(os.environ.get("DYN_CHAIN_STAGGER_MS", "0")) * 1000)
+    if stagger_us > 0:
+        from ._lib import check, load
+        for k, st in enumerate(streams):
+            if k:
+                check(load().dyn_sleep_us(min(k * stagger_us, 2000000), st.cuda_stream), "dyn_sleep_us")
     pending = list(enumerate(specs))
     results = [None] * len(specs)
     free, active = list(range(len(models)))[::-1], []

@@ -232,6 +232,11 @@ int dyn_moments(const float* x, int64_t n, float* out3, void* workspace, int64_t
 int dyn_cutout(float* x, int64_t F, int64_t T, const int32_t* rects, int64_t n_rects, int32_t mode, float value,
                float* means_scratch, void* stream);
 
+/* Device-side delay of `microseconds` on `stream` (one wave polling the 100 MHz realtime counter): starts the recording chains of
+ * lib.dynamic_eval_many out of phase.  No reference counterpart (the reference runs one recording at a time,
+ * run_dynamic_eval_full.py:84-100); scheduling aid only, computes nothing. */
+int dyn_sleep_us(int64_t microseconds, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused self-attention forward for no-grad passes (reference lcasr/lib.py:603: the final pass runs model(audio_signal) under
  * torch.no_grad(); also every epochs = 0 evaluation): out = softmax(q k^T * scale) v per (batch, head), fp32, online softmax,
