@@ -206,7 +206,7 @@ def test_bench_contract(cuda):
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["traffic"] is None or rf["traffic"] > 0
     # representative labels in the timed region, the degenerate (collapsing) labels and the boundary-faithful rate beside it
-    assert d["config"]["label_tokens_per_window"] == 400 and d["value_degenerate_labels"] > 0 and d["value_boundary"] > 0
+    assert d["config"]["label_tokens_per_window"] == 400 and d["value_degenerate_labels"] > 0 and d["value_boundary"] > 0 and d["value_online"] > d["value"]
     assert d["hyp_tokens_total"] >= 0 and "wer_counters" not in d
 
 
