@@ -313,7 +313,7 @@ def main():
             "metric": "audio-sec/s dynamic-eval (fwd+1 adapt step)", "value": round(audio_s / dt, 3), "unit": "audio-s/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "run_dynamic_eval_full: 1 h Earnings-22-shape recording per step (360000 frames, seq_len "
+            "config": {"workload": f"run_dynamic_eval_full: {a.seconds / 3600:g} h Earnings-22-shape recording per step ({n_frames} frames, seq_len "
                                    f"{a.seq_len}, overlap {a.overlap}, {'online' if a.online else 'offline'}, MADGRAD lr {a.lr}, "
                                    "6 freq masks <=34), SCConformerXL 6x768 V+1=4096 seeded weights",
                        "recording_seconds": a.seconds, "windows_per_recording": len(lib.prepare_chunks(specs[0], a.seq_len, a.overlap)[1]),
