@@ -339,8 +339,7 @@ def _dynamic_eval_gen(
             ready.record()
             if sampled == 2:
                 ready.synchronize()
-            yield ready                                      # another chain may use the host while this forward runs (the driver
-                                                             # resumes this chain once `ready` has fired)
+            yield                                            # another chain may use the host while this forward runs
             _t0 = time.perf_counter()
             if sampled == 2:
                 torch.cuda.synchronize(device)
@@ -491,30 +490,20 @@ def dynamic_eval_many(args, models, specs, seq_len, overlap, tokenizer, **kw):
     pending = list(enumerate(specs))
     results = [None] * len(specs)
     free, active = list(range(len(models)))[::-1], []
-    # Chains are serviced in order of READINESS, not round-robin: a chain yields the event it will wait for (its pseudo-label ids) and
-    # is resumed when that event has fired, so the host never blocks on one chain while another one's queue has run dry, and chains
-    # that drifted out of phase stay out of phase (a blocking round-robin re-aligns them every window).
-    poll = os.environ.get("DYN_CHAIN_POLL", "1") != "0"
     while pending or active:
         while pending and free:
             ci = free.pop()
             idx, spec = pending.pop(0)
-            active.append([_dynamic_eval_gen(args, models[ci], spec, seq_len, overlap, tokenizer, **kw), ci, idx, None])
-        progressed = False
+            active.append([_dynamic_eval_gen(args, models[ci], spec, seq_len, overlap, tokenizer, **kw), ci, idx])
         for item in list(active):
-            gen, ci, idx, waiting = item
-            if poll and waiting is not None and not waiting.query():
-                continue
-            progressed = True
+            gen, ci, idx = item
             with torch.cuda.stream(streams[ci]):
                 try:
-                    item[3] = next(gen)
+                    next(gen)
                 except StopIteration as stop:
                     results[idx] = stop.value
                     active.remove(item)
                     free.append(ci)
-        if not progressed:
-            time.sleep(0)          # every chain is waiting for the GPU: give the core away for a moment, then poll again
     for st in streams:
         main.wait_stream(st)
     return results
