@@ -14,7 +14,6 @@
 // with the previous lattice row in LDS and an 8-deep register prefetch of the slab, and the per-class reduction
 // of alpha*beta is one workgroup per time step.  All reductions run in a fixed order (no float atomics).
 #include "common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -421,11 +420,7 @@ extern "C" int dyn_ctc_loss(const float* log_probs, int64_t T, int64_t B, int64_
     hipLaunchKernelGGL(ctc_prep_kernel, dim3((unsigned)B), dim3(256), (size_t)Sm * sizeof(int32_t), st, targets, target_lengths, w.next_same, w.is_first, Sm);
     hipLaunchKernelGGL(ctc_gather_kernel, dim3((unsigned)T, (unsigned)B), dim3(256), 0, st, log_probs, targets, input_lengths,
                        target_lengths, w.slab, d);
-    // lattice positions per thread: DYN_CTC_ITEMS (1, 2, 4, 8) trades waves per workgroup (barrier cost, issue pressure on the one CU
-    // the scan runs on) against instruction-level parallelism inside a thread; default = as few items as fit 1024 threads
-    static const int items_env = [] { const char* e = getenv("DYN_CTC_ITEMS"); return e ? atoi(e) : 0; }();
     int threads = (int)((L + 63) / 64 * 64);
-    if (items_env > 1) threads = (int)((dyn::cdiv(L, items_env) + 63) / 64 * 64);
     if (threads > SCAN_T) threads = SCAN_T;
     const int items = (int)dyn::cdiv(L, threads);
     const size_t shm = (size_t)2 * L * sizeof(float);
