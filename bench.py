@@ -45,7 +45,10 @@ def parse():
     ap.add_argument("--online", type=int, default=0)
     ap.add_argument("--blank_bias", type=float, default=-1.0, help="<0: calibrate for a speech-like token rate")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_windows", type=int, default=3, help="timed CPU-oracle windows (after one untimed warm-up window)")
+    ap.add_argument("--cpu_windows", type=int, default=8, help="full windows of the ONE weight-carrying recording the CPU oracle runs "
+                    "(16384 / 14336: cpu_windows full windows + the short tail window); the first adapt step is the untimed warm-up")
+    ap.add_argument("--rendezvous_only", action="store_true", help="start the ranks, run the bench's barrier + two collectives, print "
+                    "one JSON line and exit without touching the GPU (launch-path test: tests/test_host_cpu.py)")
     ap.add_argument("--label_tokens", type=int, default=400, help="pseudo-label ids per window in the timed region: a seeded model self-training "
                     "on noise collapses to the empty transcript within a few windows (degenerate CTC lattice, L = 1), so tokenizer.encode "
                     "returns a fixed seeded sequence of this many ids per window (speech-like: ~2.4 tokens/s) and the lattice runs at "
@@ -63,6 +66,39 @@ def parse():
                     "PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
     ap.add_argument("--chains", type=int, default=3, help="independent recordings in flight per GPU (own stream + model replica)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment (the driver's own command form): start the N ranks as
+    children — one process per GPU, `python -m torch.distributed.run` on 127.0.0.1 — BEFORE this process has made any GPU call (a
+    process that has initialised HIP must never be replaced or forked into ranks), relay their output (the children inherit
+    stdout / stderr, so rank 0's JSON line is this command's JSON line) and return their exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_only(a):
+    """The N-rank launch path without the workload: process group, barrier, the max-over-ranks reduction of the timing and the
+    counter all-reduce that bench.py runs around / after its timed region."""
+    from dynamic_asr_eval_amd import dist as ddist
+    rank, local_rank, world = ddist.init()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    ddist.barrier()
+    slowest = ddist.max_over_ranks(float(rank))
+    seen = ddist.all_reduce_counts((1, rank, 0, 0))
+    ddist.barrier()
+    if rank == 0:
+        print(json.dumps({"rendezvous": True, "n_gpus": world, "ranks_seen": int(seen[0]), "rank_sum": int(seen[1]), "max_rank": slowest}), flush=True)
+    ddist.shutdown()
 
 
 def pmc_traffic():
@@ -124,14 +160,17 @@ class SubstituteLabelTokenizer:
 
 
 def cpu_baseline(a, hip_model, dev):
-    """CPU oracle (oracle/dynamic_eval_ref.py + oracle/conformer_ref.py) on a bounded sample: one untimed warm-up window, then
-    `cpu_windows` full 16384-frame windows, each = adapt step (B=2 fwd + CTC + bwd + MADGRAD) + final-pass forward + stitch; the
-    1 h recording is 169 such windows, so audio-s/s = 3600 / (169 * seconds_per_window).
-    The SAME windows then go through the HIP path (lib.dynamic_eval, same weights, same stored SpecAugment masks, the model's own
-    pseudo-labels): `parity` = the largest |log-prob difference| of the adapted, stitched outputs and whether the argmax ids agree."""
+    """CPU oracle (oracle/dynamic_eval_ref.py + oracle/conformer_ref.py) on a bounded sample: ONE recording of `cpu_windows` full
+    16384-frame windows + the short tail window at the benchmark's own seq_len / overlap, so the weights and the MADGRAD state carry
+    from window to window exactly as in the 1 h job.  Per window the oracle does an adapt step (B=2 fwd + CTC + bwd + MADGRAD) and a
+    final-pass forward + stitch; the 1 h recording is 169 such windows, so audio-s/s = 3600 / (169 * (adapt + final) seconds per
+    window), the first adapt step left out as the warm-up.
+    The SAME recording then goes through the HIP path (lib.dynamic_eval, same weights, same stored SpecAugment masks, the model's
+    own pseudo-labels), offline and online: `parity` = the largest |log-prob difference| of the adapted, stitched outputs, the
+    per-band curve of the online run (band k = rows stitched from the clean posteriors after ~k adapt steps), argmax agreement."""
     import numpy as np
     from oracle.conformer_ref import SCConformerXLRef
-    from oracle.dynamic_eval_ref import draw_masks, dynamic_eval_ref, greedy_ctc_ids
+    from oracle.dynamic_eval_ref import draw_masks, dynamic_eval_ref, greedy_ctc_ids, prepare_chunks
     from oracle.madgrad_ref import MADGRAD
     from dynamic_asr_eval_amd import lib
     from dynamic_asr_eval_amd.datasets import synthetic_spec
@@ -147,61 +186,70 @@ def cpu_baseline(a, hip_model, dev):
     model = SCConformerXLRef(vocab_size=a.vocab, seed=0, blank_bias=0.0)
     model.load_state_dict({k: v.cpu() for k, v in hip_model.state_dict().items()})    # exactly the weights the HIP path runs
     tok = SyntheticTokenizer(a.vocab)
-    n_win = a.cpu_windows + 1
-    spec = synthetic_spec(a.seq_len * n_win, seed=1234)
+    stride = a.seq_len - a.overlap
+    spec = synthetic_spec(a.seq_len + (a.cpu_windows - 1) * stride, seed=1234)
+    _, keys = prepare_chunks(spec, a.seq_len, a.overlap)
     mg = torch.Generator().manual_seed(99)
-    masks = [{0: (draw_masks(6, 34, 80, mg), ([], []))} for _ in range(n_win)]
-    outs, times = [], []
-    for w in range(n_win):
-        win = spec[:, :, w * a.seq_len:(w + 1) * a.seq_len]
-        t0 = time.time()
-        outs.append(dynamic_eval_ref(model, win, a.seq_len, 0, tok, MADGRAD, {'lr': a.lr}, {}, epochs=1, online=False, fixed_masks=masks[w]))
-        times.append(time.time() - t0)
-    timed = times[1:]
-    dt = sum(timed) / len(timed)
+    masks = {k: (draw_masks(6, 34, 80, mg), ([], [])) for k in keys}
+    tm = {}
+    want, want_online = dynamic_eval_ref(model, spec, a.seq_len, a.overlap, tok, MADGRAD, {'lr': a.lr}, {}, epochs=1, online=False,
+                                         fixed_masks=masks, timings=tm, also_online=True)
+    adapt, final = tm['adapt'][1:], tm['final'][1:]            # the first window of each loop is the warm-up
+    dt = sum(adapt) / len(adapt) + sum(final) / len(final)
     n_windows = 169
+    per = [x + y for x, y in zip(adapt, final)]
     base = {"value": round(3600.0 / (n_windows * dt), 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "seconds_per_window": [round(t, 2) for t in timed], "spread": round((max(timed) - min(timed)) / dt, 3),
-            "sample": f"{len(timed)} of {n_windows} windows after 1 warm-up window (16384 frames each: B=2 forward + CTC + backward + MADGRAD, "
-                      f"then final-pass forward + stitch) on {cores} host threads, mean {dt:.1f} s/window, extrapolated x{n_windows}"}
-    # the same windows through the HIP path
-    worst, mism, frames, min_margin = 0.0, 0, 0, None
-    hyp_h, hyp_o = [], []
-    for w in range(n_win):
+            "seconds_per_window": [round(t, 2) for t in per], "spread": round((max(per) - min(per)) / dt, 3),
+            "sample": f"{len(adapt)} of {n_windows} windows of ONE weight-carrying recording ({len(keys)} windows, seq_len {a.seq_len} / overlap "
+                      f"{a.overlap}; the first window is the warm-up): per window B=2 forward + CTC + backward + MADGRAD ({sum(adapt) / len(adapt):.1f} s) "
+                      f"and the final-pass forward + stitch ({sum(final) / len(final):.1f} s) on {cores} host threads, extrapolated x{n_windows}"}
+    # the same recording through the HIP path
+    def run(online, epochs=1):
         args = make_args(a)
-        args.spec_augment_fixed_masks = masks[w]
-        win = spec[:, :, w * a.seq_len:(w + 1) * a.seq_len].contiguous().to(dev)
-        got = lib.dynamic_eval(args, hip_model, win, a.seq_len, 0, tok, use_tqdm=False)
-        want = outs[w]
-        worst = max(worst, float(np.abs(got - want).max()))
-        bad = got.argmax(-1) != want.argmax(-1)
-        frames += bad.size
+        args.spec_augment_fixed_masks, args.online, args.epochs = masks, online, epochs
+        return lib.dynamic_eval(args, hip_model, spec.to(dev), a.seq_len, a.overlap, tok, use_tqdm=False)
+    got, got_online = run(False), run(True)
+    band = stride // 8
+
+    def cmp(g, w):
+        d = np.abs(g - w).max(-1)
+        bad = g.argmax(-1) != w.argmax(-1)
+        margin = None
         if bad.any():
-            top2 = np.sort(want[bad], -1)[:, -2:]
-            m = float((top2[:, 1] - top2[:, 0]).max())
-            min_margin = m if min_margin is None else max(min_margin, m)
-            mism += int(bad.sum())
-        hyp_h.append(tok.decode(greedy_ctc_ids(torch.from_numpy(got), a.vocab)))
-        hyp_o.append(tok.decode(greedy_ctc_ids(torch.from_numpy(want), a.vocab)))
-    # the adapted transcripts of a seeded model are (nearly) empty, so the decoded-text comparison is also made on window 0 BEFORE any
-    # adaptation (epochs = 0), where the calibrated model emits a few hundred tokens
-    a0 = make_args(a); a0.epochs = 0
-    win0 = spec[:, :, :a.seq_len]
-    want0 = dynamic_eval_ref(model, win0, a.seq_len, 0, tok, MADGRAD, {'lr': a.lr}, {}, epochs=0, online=False)
-    got0 = lib.dynamic_eval(a0, hip_model, win0.contiguous().to(dev), a.seq_len, 0, tok, use_tqdm=False)
+            top2 = np.sort(w[bad], -1)[:, -2:]
+            margin = float((top2[:, 1] - top2[:, 0]).max())
+        return d, int(bad.sum()), margin
+    d_off, bad_off, m_off = cmp(got, want)
+    d_on, bad_on, m_on = cmp(got_online, want_online)
+    hyp_h, hyp_o = tok.decode(greedy_ctc_ids(torch.from_numpy(got), a.vocab)), tok.decode(greedy_ctc_ids(torch.from_numpy(want), a.vocab))
+    # the adapted transcripts of a seeded model are (nearly) empty, so the decoded-text comparison is also made BEFORE any adaptation
+    # (epochs = 0), where the calibrated model emits a few hundred tokens per window
+    want0 = dynamic_eval_ref(model, spec, a.seq_len, a.overlap, tok, MADGRAD, {'lr': a.lr}, {}, epochs=0, online=False)
+    got0 = run(False, epochs=0)
     h0, o0 = greedy_ctc_ids(torch.from_numpy(got0), a.vocab), greedy_ctc_ids(torch.from_numpy(want0), a.vocab)
+    c0 = list(edit_counts([tok.decode(h0)], [tok.decode(o0)]))
     unadapted = {"max_abs_dlogp": float(f"{float(np.abs(got0 - want0).max()):.3e}"), "argmax_equal": bool((got0.argmax(-1) == want0.argmax(-1)).all()),
-                 "tokens": len(o0), "wer_counters_hip_vs_oracle": list(edit_counts([tok.decode(h0)], [tok.decode(o0)]))}
-    parity = {"max_abs_dlogp": float(f"{worst:.3e}"), "argmax_equal": mism == 0, "unadapted_window0": unadapted, "argmax_mismatch_frames": mism, "frames": frames,
-              "largest_oracle_margin_at_a_mismatch": min_margin, "windows": n_win,
-              "wer_counters_hip_vs_oracle": list(edit_counts(hyp_h, hyp_o)),
-              "what": "adapted + stitched log-probs of the cpu_baseline windows: HIP path vs CPU oracle, same weights and SpecAugment masks; "
-                      "wer_counters = (ins, del, sub, words) of the HIP transcripts against the oracle's"}
+                 "words": len(o0), "wer_counters_hip_vs_oracle": c0}
+    ca = list(edit_counts([hyp_h], [hyp_o]))
+    parity = {"max_abs_dlogp": float(f"{float(d_off.max()):.3e}"), "max_abs_dlogp_online": float(f"{float(d_on.max()):.3e}"),
+              "argmax_equal": bad_off == 0 and bad_on == 0, "argmax_mismatch_frames": [bad_off, bad_on], "frames": [int(d_off.shape[0]), int(d_on.shape[0])],
+              "largest_oracle_margin_at_a_mismatch": max([m for m in (m_off, m_on) if m is not None], default=None),
+              "windows": len(keys), "adapt_steps_carried": len(keys),
+              "online_max_abs_dlogp_per_band": [float(f"{float(d_on[k:k + band].max()):.2e}") for k in range(0, d_on.shape[0], band)],
+              "band_rows": band, "words": len(hyp_o.split()), "wer_counters_hip_vs_oracle": ca, "unadapted": unadapted,
+              "what": "adapted + stitched log-probs of ONE weight-carrying recording (the cpu_baseline sample): HIP path vs CPU oracle, same weights and "
+                      "SpecAugment masks, offline (final pass) and online (band k of the online curve = rows stitched after ~k adapt steps); "
+                      "wer_counters = (ins, del, sub, words) of the HIP transcript against the oracle's over `words` words (a seeded model adapts "
+                      "towards the empty transcript, so the content-bearing transcript comparison is `unadapted`)"}
     return base, parity
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:       # not under torchrun: become the launcher (nothing has touched the GPU yet)
+        sys.exit(self_launch(a))
+    if a.rendezvous_only:
+        return rendezvous_only(a)
     from dynamic_asr_eval_amd import dist as ddist, lib, ops
     from dynamic_asr_eval_amd.datasets import synthetic_spec
     from dynamic_asr_eval_amd.decoding import GreedyCTCDecoder

@@ -9,9 +9,13 @@ namespace {
 // out[s, :] = table[ids[s], :]  (+ pos[s, :] if given)
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ table,
                                                             const float* __restrict__ pos, float* __restrict__ out, int64_t S, int d,
-                                                            int64_t pos_period) {
+                                                            int64_t pos_period, int64_t vocab) {
     const int64_t s = blockIdx.x;
-    const float* row = table + (int64_t)ids[s] * d;
+    // ids are validated on the host (enc_dec.py: _check_ids) before they are uploaded; the clamp only guarantees that an id
+    // from a foreign caller can never read outside the table
+    int64_t id = ids[s];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float* row = table + id * d;
     const float* pr = pos ? pos + (s % pos_period) * d : nullptr;
     for (int c = threadIdx.x; c < d; c += blockDim.x) out[s * d + c] = row[c] + (pr ? pr[c] : 0.f);
 }
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256) void nll_grad_kernel(const float* __restrict__
                                                        int ignore_index, float scale) {
     const int64_t r = blockIdx.x;
     const int t = targets[r];
-    const bool live = t != ignore_index;
+    const bool live = t != ignore_index && t >= 0 && t < C;     // an out-of-range target contributes nothing instead of reading out of bounds
     if (threadIdx.x == 0) row_loss[r] = live ? -logp[r * C + t] : 0.f;
     if (grad == nullptr) return;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -70,7 +74,7 @@ extern "C" int dyn_embedding_fwd(const int32_t* ids, const float* table, const f
     DYN_REQUIRE(ids && table && out && S >= 0 && d > 0 && vocab > 0 && (!pos || pos_period > 0), DYN_E_ARG, "dyn_embedding_fwd: bad arguments");
     if (S == 0) return DYN_OK;
     hipLaunchKernelGGL(embedding_fwd_kernel, dim3((unsigned)S), dim3(256), 0, (hipStream_t)stream, ids, table, pos, out, S, (int)d,
-                       pos ? pos_period : 1);
+                       pos ? pos_period : 1, vocab);
     return dyn::check_launch("dyn_embedding_fwd");
 }
 

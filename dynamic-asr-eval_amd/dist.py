@@ -20,10 +20,12 @@ def local_device_index(local_rank):
     return local_rank % n if n > 0 else 0
 
 
-def init(backend=None):
-    """Initialise the default process group from the torchrun environment; returns (rank, local_rank, world)."""
+def init(backend=None, force=False):
+    """Initialise the default process group from the torchrun environment; returns (rank, local_rank, world).
+    A single process needs no group (every helper below then returns its local value); `force=True` creates the one-rank group
+    anyway, so that the collectives really go through the backend (tests/test_dist_gpu.py: RCCL on the box's one GPU)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             # DYN_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks
             backend = os.environ.get("DYN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -33,6 +35,12 @@ def init(backend=None):
             torch.cuda.set_device(local_device_index(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def shutdown():
+    """Destroy the default group (a process that initialised RCCL should tear it down before it exits)."""
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def shard_longest_first(lengths, world):
@@ -56,7 +64,7 @@ def _device_for(backend_tensor_device=None):
 
 def all_reduce_counts(counts):
     """Sum the 4 int64 edit counters (ins, del, sub, words) over ranks — the one collective of the path."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return tuple(int(c) for c in counts)
     t = torch.tensor(list(counts), dtype=torch.int64, device=_device_for())
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -65,7 +73,7 @@ def all_reduce_counts(counts):
 
 def gather_records(records):
     """Gather per-recording result dicts (id, hypothesis, gold, elapsed) to every rank, ordered by recording index."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return sorted(records, key=lambda r: r["index"])
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, records)
@@ -74,7 +82,7 @@ def gather_records(records):
 
 
 def max_over_ranks(value):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=_device_for())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -82,7 +90,7 @@ def max_over_ranks(value):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         if dist.get_backend() == "nccl":
             dist.barrier(device_ids=[torch.cuda.current_device()])   # RCCL: name the device instead of letting torch guess it
         else:

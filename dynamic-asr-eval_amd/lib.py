@@ -305,10 +305,9 @@ def _dynamic_eval_gen(
         epochs_stime = time.time()
         pbar = tqdm(training_keys) if use_tqdm else training_keys
         for i in pbar:
-            sampled = ops.gemm_profile_tick()   # bench.py's live roofline sampling (0 = off)
-            if sampled == 2:
-                torch.cuda.synchronize(device)   # exclusive sample: the other chains' queued work drains first
-            ops.gemm_profile_mode(sampled)
+            sampled = 0
+            if ops.gemm_profile_active():        # bench.py's live roofline sampling; everything it needs in the loop is in these blocks
+                sampled = ops.gemm_profile_begin_step(device)
             view = training_data[i][0]  # [F, u_len] view into the recording
             u_len = view.shape[-1]
             audio_chunk = torch.empty(num_negatives + 1, Fq, u_len, device=device, dtype=torch.float32)
@@ -337,15 +336,14 @@ def _dynamic_eval_gen(
             pinned[1].copy_(n_dev, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record()
-            if sampled == 2:
-                ready.synchronize()
+            if sampled:
+                ops.gemm_profile_before_yield(sampled, ready)
             yield                                            # another chain may use the host while this forward runs
             _t0 = time.perf_counter()
-            if sampled == 2:
-                torch.cuda.synchronize(device)
+            if ops.gemm_profile_active():        # also for unsampled steps: the mode is per model call, chains interleave on this thread
+                ops.gemm_profile_resume_step(device, sampled)
             ready.synchronize()
             HOST_WAIT[0] += time.perf_counter() - _t0
-            ops.gemm_profile_mode(sampled)
             pseudo_targets = tokenizer.decode(pinned[0][0, :int(pinned[1][0])].tolist())
             if verbose and not args.__dict__.get('not_verbose', False) and args.__dict__.get('print_predictions', False):
                 print(f'Pseudo targets: {pseudo_targets}')
@@ -388,8 +386,8 @@ def _dynamic_eval_gen(
 
             if online:
                 stitch_window(i, post[-1].detach(), u_len)
-            if sampled == 2:
-                torch.cuda.current_stream(device).synchronize()
+            if sampled:
+                ops.gemm_profile_end_step(device, sampled)
         epochs_etime = time.time()
         if print_runtimes:
             torch.cuda.synchronize(device)
@@ -409,10 +407,9 @@ def _dynamic_eval_gen(
             while len(group) < final_batch and idx + len(group) < len(keys) and \
                     training_data[keys[idx + len(group)]].shape[-1] == u_len:
                 group.append(keys[idx + len(group)])
-            sampled = ops.gemm_profile_tick()
-            if sampled == 2:
-                torch.cuda.synchronize(device)
-            ops.gemm_profile_mode(sampled)
+            sampled = 0
+            if ops.gemm_profile_active():
+                sampled = ops.gemm_profile_begin_step(device)
             batch = torch.empty(len(group), Fq, u_len, device=device, dtype=torch.float32)
             for b, k in enumerate(group):
                 batch[b].copy_(training_data[k][0])
@@ -421,8 +418,8 @@ def _dynamic_eval_gen(
                 for b, k in enumerate(group):
                     stitch_window(k, post[b], u_len)
             idx += len(group)
-            if sampled == 2:
-                torch.cuda.current_stream(device).synchronize()
+            if sampled:
+                ops.gemm_profile_end_step(device, sampled)
             yield                                        # independent forwards are queued: let another chain enqueue
         if print_runtimes:
             torch.cuda.synchronize(device)

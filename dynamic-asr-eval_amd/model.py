@@ -88,6 +88,18 @@ def param_spec(cfg, num_classes):
     return spec
 
 
+def _parse_fused_attn_grad(value):
+    """DYN_FUSED_ATTN_GRAD / `model.fused_attention_grad`: 0 = never, 1 = always, n > 1 = from T' >= n frames.  Validated where
+    it is set, so a typo fails at construction instead of in the middle of a forward."""
+    try:
+        mode = int(str(value).strip())
+    except ValueError:
+        raise ValueError(f"DYN_FUSED_ATTN_GRAD / fused_attention_grad must be 0, 1 or a frame threshold, got {value!r}") from None
+    if mode < 0:
+        raise ValueError(f"DYN_FUSED_ATTN_GRAD / fused_attention_grad must be >= 0, got {value!r}")
+    return mode
+
+
 class _Group:
     """A named slice of the parameter list (`model.subsampling`, `model.layers[i]`, `model.decoder`): what the
     reference's freeze helpers iterate (reference lcasr/lib.py:163-204)."""
@@ -156,7 +168,7 @@ class SCConformerXL:
         self._wq = None
         # grad-mode attention without the [B, H, T', T'] score matrix (forward keeps one log-sum-exp per row, the backward re-forms P
         # tile by tile: 7 products instead of 4): "0" never, "1" always, otherwise from T' >= this many frames
-        self.fused_attention_grad = os.environ.get("DYN_FUSED_ATTN_GRAD", "4096")
+        self.fused_attention_grad = _parse_fused_attn_grad(os.environ.get("DYN_FUSED_ATTN_GRAD", "4096"))
         self.training = False
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -227,7 +239,8 @@ class SCConformerXL:
         must then stay unmodified until the queue is flushed (the residual-stream gradient gets a new buffer per module)."""
         wg = self.trainable(wname) and not self._skip_wgrad
         bg = bname is not None and self.trainable(bname) and not self._skip_wgrad   # bitfit trains a bias under a frozen weight
-        if wg and self._wq is not None and (wname.startswith("layers.") or wname == "subsampling.out.weight"):
+        if wg and self._wq is not None and (wname.startswith("layers.") or wname == "subsampling.out.weight") \
+                and ops.wgrad_groupable(dy, x, self.G[wname]):
             self._wq.append(ops.wgrad_desc(dy, x, self.G[wname], alpha=alpha, beta=1.0, colsum=self.G[bname] if bg else None, colsum_beta=1.0))
             bg = False
         elif wg:
@@ -240,6 +253,16 @@ class SCConformerXL:
             return ops.linear_dgrad(dy, self.P[wname], alpha=alpha, epilogue=ops.EPI_SILU_GRAD, aux=silu_of)
         dx = ops.linear_dgrad(dy, self.P[wname], alpha=alpha)
         return ops.silu_bwd(silu_of, dx, out=dx) if silu_of is not None else dx
+
+    def _check_not_queued(self, t, what):
+        """An in-place update of `t` while a queued weight-gradient descriptor still reads it would corrupt that gradient (the
+        descriptors hold raw pointers until the flush at the end of the backward): refuse instead of computing garbage."""
+        if self._wq:
+            lo, hi = t.data_ptr(), t.data_ptr() + t.numel() * 4
+            for d in self._wq:
+                for src in d._keep[:2]:
+                    if src is not None and src.data_ptr() < hi and lo < src.data_ptr() + src.numel() * 4:
+                        raise ops.DynError(f"backward: in-place update of {what} while a deferred weight gradient still reads it")
 
     def _res_norm_bwd(self, h, wn, bn_, mean, rstd, dn, dh):
         """dh_out = dh + LayerNorm_bwd(dn): in place, or into a NEW buffer while weight gradients that read dh are still queued."""
@@ -417,8 +440,8 @@ class SCConformerXL:
         return out
 
     def _fused_grad_attention(self, T):
-        mode = str(self.fused_attention_grad)
-        return mode == "1" or (mode != "0" and T >= int(mode))
+        mode = _parse_fused_attn_grad(self.fused_attention_grad)     # tests and harnesses may assign the attribute directly
+        return mode == 1 or (mode != 0 and T >= mode)
 
     def _cnorm_fwd(self, c, p):
         cfg, P = self.config, self.P
@@ -531,6 +554,7 @@ class SCConformerXL:
         ops.layernorm_bwd(h, P["decoder.norm.weight"], mean, rstd, dn, dh, G["decoder.norm.weight"], G["decoder.norm.bias"],
                           dx_beta=0.0)
         if getattr(self, "_grad_hidden", None) is not None:
+            self._check_not_queued(dh, "the encoder-state gradient")
             ops.axpby(self._grad_hidden.contiguous(), dh, a=1.0, b=1.0)
         nl = cfg["n_layers"]
         for l in reversed(range(nl)):
@@ -539,6 +563,7 @@ class SCConformerXL:
                 dp = self._lin_bwd(dh, pz, "decoder.reproj.weight", "decoder.reproj.bias")
                 dzz = ops.softmax_bwd(pz, dp, out=dp)
                 dn = self._lin_bwd(dzz, n, "decoder.ff.weight", "decoder.ff.bias")
+                self._check_not_queued(dh, "the residual-stream gradient (self-conditioning branch)")
                 ops.layernorm_bwd(h0, P["decoder.norm.weight"], mean, rstd, dn, dh, G["decoder.norm.weight"],
                                   G["decoder.norm.bias"], dx_beta=1.0)
             lc = ctx["layers"][l]

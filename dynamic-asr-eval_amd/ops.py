@@ -177,8 +177,24 @@ def wgrad_desc(dy, x, dw, alpha=1.0, beta=1.0, colsum=None, colsum_beta=1.0):
     return d
 
 
+MAX_GROUPS = 96     # kMaxGroups of csrc/gemm_f32.hip: descriptors per dyn_gemm_f32_grouped launch
+
+
+def wgrad_groupable(dy, x, dw):
+    """True when dw = dy^T @ x may ride in the grouped launch: dyn_gemm_f32_grouped has only the 16-byte vector staging, so it
+    needs leading dimensions that are multiples of 4 (the single-GEMM path degrades to scalar staging instead of failing)."""
+    N, K = dw.shape
+    return N % 4 == 0 and K % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+
+
 def gemm_grouped(descs):
-    """One launch over the 128x128 tiles of all `descs` (dyn_gemm_f32_grouped): the deferred weight gradients of a backward pass."""
+    """One launch over the 128x128 tiles of all `descs` (dyn_gemm_f32_grouped): the deferred weight gradients of a backward pass.
+    More than MAX_GROUPS descriptors (8 per conformer block + 1: from 12 blocks on) go out in slices of MAX_GROUPS; the slices are
+    stream-ordered, so they can share the descriptor-table workspace."""
+    if len(descs) > MAX_GROUPS:
+        for i in range(0, len(descs), MAX_GROUPS):
+            gemm_grouped(descs[i:i + MAX_GROUPS])
+        return
     n = len(descs)
     if n == 0:
         return
@@ -241,6 +257,38 @@ def gemm_profile_mode(kind):
     if prof is not None:
         prof["eager_now"] = kind > 0
         prof["exclusive_now"] = kind == 2
+
+
+def gemm_profile_active():
+    """True only while bench.py's sampling is on: the dynamic-eval loop enters its sampling blocks under this test and nowhere else."""
+    return GEMM_PROFILE is not None
+
+
+def gemm_profile_begin_step(device):
+    """Start of a window step (or final-pass batch): -> 0 not sampled / 1 sampled shared / 2 sampled exclusively (device drained first)."""
+    kind = gemm_profile_tick()
+    if kind == 2:
+        torch.cuda.synchronize(device)           # exclusive sample: the other chains' queued work drains first
+    gemm_profile_mode(kind)
+    return kind
+
+
+def gemm_profile_before_yield(kind, ready_event):
+    if kind == 2:
+        ready_event.synchronize()                # keep the device to this chain until its forward has finished
+
+
+def gemm_profile_resume_step(device, kind):
+    """After the yield of a sampled step: other chains may have queued work meanwhile; the mode is per model call."""
+    if kind == 2:
+        torch.cuda.synchronize(device)
+    gemm_profile_mode(kind)
+
+
+def gemm_profile_end_step(device, kind):
+    if kind == 2:
+        torch.cuda.current_stream(device).synchronize()
+    gemm_profile_mode(0)
 
 
 def gemm_profile_stop():

@@ -105,8 +105,13 @@ def stitch_ref(model_outputs, all_logits, logit_count):
 
 def dynamic_eval_ref(model, spec, seq_len, overlap, tokenizer, optimizer_cls, lr_args, spec_augment_config, epochs=1,
                      shuffle=False, online=False, downsampling_factor=8, fixed_masks=None, return_params=False,
-                     max_windows=None):
-    """`max_windows` (benchmarks only) stops the adaptation loop after that many windows."""
+                     max_windows=None, timings=None, also_online=False):
+    """`max_windows` (benchmarks only) stops the adaptation loop after that many windows.
+    `timings` (benchmarks only): a dict that receives 'adapt' / 'final' = seconds per window of the two loops.
+    `also_online` (tests only, offline mode): the adaptation loop is the same in both modes, so one run can also hand back what
+    `online=True` would have stitched (the clean copy's posteriors of every adapt step, lib.py:583-589) -> (offline, online[, params]).
+    A float64 model / spectrogram runs the whole loop in float64 (the noise-floor reference of scripts/drift_check.py)."""
+    import time
     spec_n = spec.shape[-1]
     original_model_params = [p.clone().detach().cpu() for p in model.parameters()]
     num_negatives = 1
@@ -116,12 +121,13 @@ def dynamic_eval_ref(model, spec, seq_len, overlap, tokenizer, optimizer_cls, lr
     if seq_len > spec_n:
         seq_len, overlap = spec_n, 0
     assert overlap / downsampling_factor == overlap // downsampling_factor
-    all_logits = torch.zeros((1, spec_n // 4 + seq_len, tokenizer.vocab_size() + 1))
-    logit_count = torch.zeros((1, spec_n // 4 + seq_len, tokenizer.vocab_size() + 1))
+    all_logits = torch.zeros((1, spec_n // 4 + seq_len, tokenizer.vocab_size() + 1), dtype=spec.dtype)
+    logit_count = torch.zeros((1, spec_n // 4 + seq_len, tokenizer.vocab_size() + 1), dtype=spec.dtype)
     loop_epochs = epochs                   # the reference's loop runs `range(args.epochs)` (lib.py:527) ...
     epochs = 1 if online else epochs       # ... although the printed count is forced to 1 in online mode (lib.py:515)
     shuffle = False if online else shuffle
     model_outputs = {}                     # online: overwritten by every epoch, so the LAST epoch is what gets stitched (lib.py:583-589)
+    online_outputs = {}                    # also_online: what online=True would have kept
     model.eval()
     training_data, training_keys = prepare_chunks(spec, seq_len, overlap)
     n_done = 0
@@ -132,6 +138,7 @@ def dynamic_eval_ref(model, spec, seq_len, overlap, tokenizer, optimizer_cls, lr
             if max_windows is not None and n_done >= max_windows:
                 break
             n_done += 1
+            t_win = time.perf_counter()
             audio_chunk = training_data[i].clone()
             audio_chunk = audio_chunk.repeat(num_negatives + 1, 1, 1)
             F_, u_len = audio_chunk.shape[1], audio_chunk.shape[-1]
@@ -155,14 +162,17 @@ def dynamic_eval_ref(model, spec, seq_len, overlap, tokenizer, optimizer_cls, lr
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()
-            if online:
+            if online or also_online:
                 logits = torch.exp(out['final_posteriors'][-1].detach())
                 ds_len = logits.shape[-2]
-                model_outputs[i] = {'logits': logits, 'ds_len': ds_len, 'overlap_ds': int(overlap / (u_len / ds_len))}
+                (model_outputs if online else online_outputs)[i] = {'logits': logits, 'ds_len': ds_len, 'overlap_ds': int(overlap / (u_len / ds_len))}
+            if timings is not None:
+                timings.setdefault('adapt', []).append(time.perf_counter() - t_win)
     if not online:
         model.eval()
         training_data, training_keys = prepare_chunks(spec, seq_len, overlap)
         for i in training_keys:
+            t_win = time.perf_counter()
             audio_chunk = training_data[i].clone()
             u_len = audio_chunk.shape[-1]
             with torch.no_grad():
@@ -170,10 +180,16 @@ def dynamic_eval_ref(model, spec, seq_len, overlap, tokenizer, optimizer_cls, lr
             logits = torch.exp(out['final_posteriors'][0].detach())
             ds_len = logits.shape[-2]
             model_outputs[i] = {'logits': logits, 'ds_len': ds_len, 'overlap_ds': int(overlap / (u_len / ds_len))}
+            if timings is not None:
+                timings.setdefault('final', []).append(time.perf_counter() - t_win)
     logits = stitch_ref(model_outputs, all_logits, logit_count)
     if return_params:
         updated = [p.clone().detach().cpu() for p in model.parameters()]
     for p, p_orig in zip(model.parameters(), original_model_params):
         p.data = p_orig.data.to(p.device)
-    out = logits.squeeze(0).numpy().astype(np.float32)
+    keep = np.float64 if spec.dtype == torch.float64 else np.float32
+    out = logits.squeeze(0).numpy().astype(keep)
+    if also_online and not online:
+        out_online = stitch_ref(online_outputs, torch.zeros_like(all_logits), torch.zeros_like(logit_count)).squeeze(0).numpy().astype(keep)
+        return (out, out_online, updated) if return_params else (out, out_online)
     return (out, updated) if return_params else out

@@ -328,3 +328,65 @@ def test_product_package_never_imports_the_oracle():
             "try:\n    _lib.load()\nexcept _lib.DynError as e:\n    print('DynError', 'no CPU fallback' in str(e))\n") % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.stdout.strip() == "DynError True", out.stdout + out.stderr
+
+
+def test_bench_gpus2_self_launches_its_ranks_and_rendezvous():
+    """`python bench.py --gpus 2` is the driver's command form: with no torchrun environment bench.py must start the ranks itself
+    (before any GPU call) and relay rank 0's JSON line.  --rendezvous_only stops after the process group, the barrier and the two
+    collectives of the bench (no GPU needed): 2 gloo ranks here."""
+    env = dict(os.environ, DYN_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous_only"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res == {"rendezvous": True, "n_gpus": 2, "ranks_seen": 2, "rank_sum": 1, "max_rank": 1.0}
+
+
+def test_one_rank_group_runs_the_collectives_through_the_backend():
+    """dist.init(force=True) creates the one-rank group; the helpers then go through the backend instead of short-circuiting
+    (gloo here; tests/test_dist_gpu.py does the same through RCCL on the GPU box)."""
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "import torch.distributed as dist\n"
+            "from dynamic_asr_eval_amd import dist as ddist\n"
+            "assert ddist.all_reduce_counts((1, 2, 3, 4)) == (1, 2, 3, 4) and not dist.is_initialized()\n"
+            "ddist.init(backend='gloo', force=True); assert dist.is_initialized() and dist.get_world_size() == 1\n"
+            "assert ddist.all_reduce_counts((1, 2, 3, 4)) == (1, 2, 3, 4) and ddist.max_over_ranks(1.5) == 1.5\n"
+            "assert [r['index'] for r in ddist.gather_records([{'index': 2}, {'index': 1}])] == [1, 2]\n"
+            "ddist.barrier(); ddist.shutdown(); assert not dist.is_initialized(); print('OK')\n" % ROOT)
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
+
+
+def test_grouped_wgrad_queue_is_sliced_for_deep_models():
+    """8 weight-gradient descriptors per block + 1 exceed the 96 groups of one dyn_gemm_f32_grouped launch from 12 blocks
+    on; ops.gemm_grouped must cut the queue into launches of <= MAX_GROUPS (checked on the host: the C call is replaced)."""
+    from dynamic_asr_eval_amd import ops
+    from dynamic_asr_eval_amd._lib import GemmDesc
+    calls = []
+
+    class FakeLib:
+        def dyn_gemm_f32_grouped(self, arr, n, ws, ws_bytes, stream):
+            calls.append(int(n))
+            return 0
+    descs = []
+    for _ in range(8 * 12 + 1):
+        d = GemmDesc(); d.M, d.N, d.K = 4, 4, 4
+        descs.append(d)
+    old = (ops._L, ops.workspace, ops._stream)
+    ops._L, ops.workspace, ops._stream = (lambda: FakeLib()), (lambda *a, **k: torch.empty(1024, dtype=torch.uint8)), (lambda: 0)
+    try:
+        ops.gemm_grouped(descs)
+    finally:
+        ops._L, ops.workspace, ops._stream = old
+    assert calls == [96, 1] and ops.MAX_GROUPS == 96
+
+
+def test_fused_attention_grad_switch_is_validated_where_it_is_set():
+    from dynamic_asr_eval_amd.model import _parse_fused_attn_grad
+    assert [_parse_fused_attn_grad(v) for v in ("0", "1", "4096", 2048, " 8192 ")] == [0, 1, 4096, 2048, 8192]
+    for bad in ("auto", "", "-1", "1.5"):
+        with pytest.raises(ValueError):
+            _parse_fused_attn_grad(bad)

@@ -132,6 +132,55 @@ def test_dynamic_eval_parity(cuda, online, optim_name):
         assert (a - b).abs().max().item() < 5e-5
 
 
+class _RecordingTokenizer:
+    """The reference's own 128-piece SentencePiece model (tests/golden/tokenizer_128.model) with the target lengths of every
+    encode() recorded: the text hop ids -> text -> ids of reference lcasr/lib.py:565-569 with a real tokenizer."""
+
+    def __init__(self):
+        import os
+        from dynamic_asr_eval_amd.tokenizer import load_sentencepiece
+        self.sp = load_sentencepiece(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tokenizer_128.model"))
+        self.lengths = []
+
+    def vocab_size(self):
+        return self.sp.vocab_size()
+
+    def decode(self, ids):
+        return self.sp.decode([int(i) for i in ids])
+
+    def encode(self, text):
+        ids = self.sp.encode(text)
+        self.lengths.append(len(ids))
+        return ids
+
+
+def test_dynamic_eval_with_the_128_piece_tokenizer_reaches_the_wide_ctc_lattices(cuda):
+    """The loop itself at lattice widths L = 2 S + 1 > 1024 and > 2048: with the reference's tokenizer a 164 s window of a model
+    that emits a token every other frame carries ~1000 pseudo-label ids (1030 -> ctc_scan_kernel<4>, 1002 -> <2>), the 82 s tail
+    window ~500; the stitched, adapted log-probs must match the oracle loop (torch.nn.CTCLoss on the CPU)."""
+    from oracle import dynamic_eval_ref as R
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import lib
+    ref, hip = _pair(cuda, SMALL, vocab=128, seed=5, blank_bias=0.0)
+    spec = torch.randn(1, 80, 16384 + 8192, generator=torch.Generator().manual_seed(3))
+    seq_len, overlap = 16384, 8192
+    _, keys = R.prepare_chunks(spec, seq_len, overlap)
+    assert len(keys) == 3
+    masks = _masks_for(keys, 80, None, seed=4)
+    tok_ref, tok_hip = _RecordingTokenizer(), _RecordingTokenizer()
+    out_ref = R.dynamic_eval_ref(ref, spec, seq_len, overlap, tok_ref, MADGRAD_REF, {'lr': 2e-6}, {}, epochs=1, shuffle=False,
+                                 online=False, fixed_masks=masks)
+    args = _args(optim_lr=2e-6, epochs=1, shuffle=False, online=False, spec_augment_fixed_masks=masks, quiet=True)
+    out = lib.dynamic_eval(args, hip, spec, seq_len, overlap, tok_hip, use_tqdm=False)
+    assert tok_hip.lengths == tok_ref.lengths, (tok_hip.lengths, tok_ref.lengths)
+    # S in [512, 1023] -> L in (1024, 2048] -> ctc_scan_kernel<2>; S in [1024, 2047] -> ctc_scan_kernel<4>   (seeded: [1030, 1002, 510])
+    assert any(1024 <= n <= 2047 for n in tok_hip.lengths) and any(512 <= n <= 1023 for n in tok_hip.lengths), \
+        f"pseudo-label lengths {tok_hip.lengths}: expected one window in [512, 1023] and one in [1024, 2047]"
+    err = np.abs(out - out_ref).max()
+    assert out.shape == out_ref.shape and err < 1e-3, f"adapted, stitched log-probs differ by {err} (bar: 1e-3 fp32)"
+    assert np.array_equal(out.argmax(-1), out_ref.argmax(-1)), "CTC argmax ids must be bit-exact"
+
+
 def test_dynamic_eval_short_recording_and_epochs0(cuda):
     """spec_n <= seq_len -> single window; epochs=0 -> plain forward + stitch (the no-adapt baseline path)."""
     from oracle import dynamic_eval_ref as R

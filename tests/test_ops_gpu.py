@@ -196,8 +196,14 @@ def test_ctc_greedy_bit_exact(cuda, T, C):
         assert ids[b, :len(ref)].cpu().tolist() == ref
 
 
+# lattice width L = 2 S + 1 selects the scan kernel (csrc/ctc.hip: 1024-thread workgroup, ITEMS = ceil(L / 1024) positions per thread):
+# S <= 511 -> ctc_scan_kernel<1>, 512..1023 -> <2>, 1024..2047 -> <4>, 2048..4095 -> <8>.  The last six cases execute <2>, <4>, <8>
+# (the prefetch-depth 4 / 2 variants), with repeated labels, a shorter second sample and both reductions.
 @pytest.mark.parametrize("T,C,S,reduction", [(64, 129, 10, "sum"), (50, 33, 0, "sum"), (200, 129, 60, "mean"),
-                                            (512, 4096, 255, "sum"), (30, 20, 12, "sum")])
+                                            (512, 4096, 255, "sum"), (30, 20, 12, "sum"),
+                                            (2048, 4096, 600, "sum"), (1300, 129, 600, "mean"),
+                                            (2048, 129, 1100, "sum"), (2300, 33, 1100, "mean"),
+                                            (4200, 129, 2100, "sum"), (4300, 33, 2100, "mean")])
 def test_ctc_loss_and_grad(cuda, T, C, S, reduction):
     from dynamic_asr_eval_amd import ops
     B = 2
@@ -207,7 +213,12 @@ def test_ctc_loss_and_grad(cuda, T, C, S, reduction):
     if S >= 4:
         tgt[0, 1] = tgt[0, 0]  # repeated label needs a blank between
         tgt[1, 3] = tgt[1, 1]
-    tl = torch.tensor([S, max(S - 2, 0)]) if S else torch.tensor([0, 0])
+    if S >= 512:               # repeats across the 1024-position item boundaries of the wide scans, and a run of three
+        for k in (511, 512, 1023, 1024, 2047):
+            if k + 1 < S:
+                tgt[0, k + 1] = tgt[0, k]
+        tgt[1, 700 % S] = tgt[1, 700 % S - 1] = tgt[1, 700 % S - 2]
+    tl = torch.tensor([S, max(S - S // 3 - 2, 0)]) if S >= 512 else torch.tensor([S, max(S - 2, 0)]) if S else torch.tensor([0, 0])
     il = torch.tensor([T, T - 3])
     lpr = lp.clone().requires_grad_()
     loss_ref = F.ctc_loss(lpr.transpose(0, 1), tgt[:, :max(S, 1)], il, tl, blank=C - 1, reduction=reduction)
@@ -217,7 +228,8 @@ def test_ctc_loss_and_grad(cuda, T, C, S, reduction):
                                    reduction=reduction, grad_scale=scale)
     rel = abs(loss.item() - loss_ref.item()) / max(1.0, abs(loss_ref.item()))
     assert rel < 2e-6 * max(1, T // 64), (loss.item(), loss_ref.item())   # fp32 lattice, T serial log-sum-exps
-    _close(grad, lpr.grad, 2e-5 * scale * T, "ctc grad")                 # |grad| <= scale per element
+    # |grad| <= scale per element; the fp32 lattice's log-domain error grows with the T serial log-sum-exps
+    _close(grad, lpr.grad, scale * max(1.3e-3, 2e-6 * T), "ctc grad")
 
 
 def test_optimizers_match_torch(cuda):
