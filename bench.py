@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_windows", type=int, default=8, help="full windows of the ONE weight-carrying recording the CPU oracle runs "
                     "(16384 / 14336: cpu_windows full windows + the short tail window); the first adapt step is the untimed warm-up")
+    ap.add_argument("--side_workloads", type=int, default=1, help="1: after the timed region (never part of `value`) also time the other "
+                    "paths of the same C-ABI on short synthetic inputs and print their audio-s/s under `other_workloads`: AWMC "
+                    "(lcasr/lib.py:206-376), wav2vec2-base dynamic_eval_su (wav2vec2/lib.py:293-462), enc-dec teacher_ce (lcasr/lib.py:1475-1732)")
     ap.add_argument("--rendezvous_only", action="store_true", help="start the ranks, run the bench's barrier + two collectives, print "
                     "one JSON line and exit without touching the GPU (launch-path test: tests/test_host_cpu.py)")
     ap.add_argument("--label_tokens", type=int, default=400, help="pseudo-label ids per window in the timed region: a seeded model self-training "
@@ -244,6 +247,70 @@ def cpu_baseline(a, hip_model, dev):
     return base, parity
 
 
+def other_workloads(a, model, dev):
+    """Driver-visible throughput of the path's other loops (one recording each, one chain, second of two runs; untimed as far as
+    `value` goes).  Same kernels, same C-ABI; shapes: AWMC on a 10-min recording of the benchmark's model and window; wav2vec2-base
+    (Wav2Vec2Config() defaults, seeded) `dynamic_eval_su` over a 5-min TEDLIUM-shape talk cut by the reference's fetch_utterances
+    rule; enc-dec `teacher_ce` (6 x 768 encoder + 2 x 256 decoder, seeded) on a 5-min recording, 2048-frame windows."""
+    import io
+    from contextlib import redirect_stdout
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.datasets import synthetic_spec
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    out = {}
+
+    def best_of_two(fn):
+        ts = []
+        for _ in range(2):
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            with redirect_stdout(io.StringIO()):       # the mirrored loops print what the reference prints
+                fn()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t)
+        return min(ts)
+
+    try:
+        secs = 600.0
+        spec = synthetic_spec(int(secs * 100), seed=4242).to(dev)
+        args = make_args(a)
+        tok = SyntheticTokenizer(a.vocab)
+        dt = best_of_two(lambda: lib.AWMC(args, model, spec, a.seq_len, a.overlap, tok, use_tqdm=False, return_device=True))
+        out["awmc"] = {"value": round(secs / dt, 1), "unit": "audio-s/s", "sample": f"{secs:.0f} s recording, seq_len {a.seq_len} / overlap {a.overlap}, 1 chain"}
+    except Exception as e:                              # a side measurement must never take the headline down with it
+        out["awmc"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    try:
+        from dynamic_asr_eval_amd import run_wav2vec2 as RW, wav2vec2_lib as W
+        from dynamic_asr_eval_amd.wav2vec2_model import Wav2Vec2ForCTC
+        wm = Wav2Vec2ForCTC(None, device=dev)
+        RW.init_synthetic(wm, 0)
+        wm.eval()
+        utts = RW.fetch_utterances_synthetic(300.0, 7)
+        audio_s = sum(u['waveform'].shape[-1] for u in utts) / 16000.0
+        wargs = argparse.Namespace(epochs=1, shuffle=False)
+        dt = best_of_two(lambda: W.dynamic_eval_su(wargs, wm, [dict(u) for u in utts], 0, 0, W.CharTokenizer(), None, use_tqdm=False, optim=W.MADGRAD,
+                                                   lr_args={'lr': 1e-6}))
+        out["wav2vec2_su"] = {"value": round(audio_s / dt, 1), "unit": "audio-s/s", "sample": f"{len(utts)} utterances, {audio_s:.0f} s of 16 kHz audio, wav2vec2-base shape"}
+        del wm
+    except Exception as e:
+        out["wav2vec2_su"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    try:
+        from dynamic_asr_eval_amd.enc_dec import EncDecSCConformerXL, enc_dec_dynamic_eval
+        from dynamic_asr_eval_amd.synthetic_weights import init_synthetic
+        em = EncDecSCConformerXL({}, vocab_size=a.vocab, device=dev)
+        init_synthetic(em, seed=1, blank_bias=1.0)
+        secs = 300.0
+        spec = synthetic_spec(int(secs * 100), seed=4243).to(dev)
+        eargs = make_args(a)
+        eargs.training_mode = 'teacher_ce'
+        dt = best_of_two(lambda: enc_dec_dynamic_eval(eargs, em, spec, 2048, 0, SyntheticTokenizer(a.vocab), use_tqdm=False))
+        out["enc_dec_teacher_ce"] = {"value": round(secs / dt, 1), "unit": "audio-s/s", "sample": f"{secs:.0f} s recording, 2048-frame windows, KV-cached greedy teacher + final decode"}
+        del em
+    except Exception as e:
+        out["enc_dec_teacher_ce"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:       # not under torchrun: become the launcher (nothing has touched the GPU yet)
@@ -388,6 +455,8 @@ def main():
         }
         out.update(side)
         out["config"]["label_tokens_per_window"] = a.label_tokens
+        if world == 1 and a.side_workloads:
+            out["other_workloads"] = other_workloads(a, model, dev)
         if world == 1 and not a.no_cpu_baseline:
             for m in models:                                           # the parity leg runs on the bench's own (restored) weights
                 m.use_graphs = bool(a.graphs)

@@ -63,7 +63,7 @@ def check(rc, what=""):
 
 
 _CTYPES = {
-    "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+    "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "uint64_t": ctypes.c_uint64,
 }
 _PROTOS = None
 

@@ -59,6 +59,45 @@ __global__ __launch_bounds__(256) void nll_grad_kernel(const float* __restrict__
     }
 }
 
+// ---- counter-based randomness: a draw is a pure function of (seed, stream, index); see include/dyneval.h
+__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t stream, uint64_t index) {
+    uint64_t z = seed ^ ((stream + 1) * 0x9E3779B97F4A7C15ull) ^ ((index + 1) * 0xC2B2AE3D27D4EB4Full);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p, float scale,
+                                                      uint64_t seed, uint64_t stream) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float u = (float)(mix64(seed, stream, (uint64_t)i) >> 40) * 5.9604644775390625e-8f;   // 24 bits * 2^-24: exact in fp32
+        y[i] = u >= p ? x[i] * scale : 0.f;
+    }
+}
+
+// ids[row] = argmax_c (x[row, c] * inv_t + gumbel(seed, step0 + row, c)), first maximum wins
+__global__ __launch_bounds__(256) void gumbel_argmax_rows_kernel(const float* __restrict__ x, int32_t* __restrict__ ids, int64_t rows, int C,
+                                                                 int64_t ld, float inv_t, uint64_t seed, uint64_t step0) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float* xr = x + row * ld;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            const float u = (float)(2 * (mix64(seed, step0 + (uint64_t)row, (uint64_t)c) >> 41) + 1) * 5.9604644775390625e-8f;  // odd / 2^24 in (0, 1)
+            const float v = xr[c] * inv_t - logf(-logf(u));
+            if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) ids[row] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+
 __global__ void sum_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
     __shared__ float red[16];
     float s = 0.f;
@@ -103,4 +142,24 @@ extern "C" int dyn_nll_loss(const float* log_probs, const int32_t* targets, floa
                            (int)ignore_index, grad_scale);
     hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, st, row_loss, loss, rows);
     return dyn::check_launch("dyn_nll_loss");
+}
+
+extern "C" int dyn_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream) {
+    DYN_REQUIRE(x && y && n >= 0 && p >= 0.f && p < 1.f, DYN_E_ARG, "dyn_dropout: need 0 <= p < 1");
+    if (n == 0) return DYN_OK;
+    int64_t g = dyn::cdiv(n, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, y, n, p, 1.0f / (1.0f - p), seed, stream_id);
+    return dyn::check_launch("dyn_dropout");
+}
+
+extern "C" int dyn_gumbel_argmax_rows(const float* x, int64_t rows, int64_t C, int64_t ld, float inv_temperature, uint64_t seed,
+                                      uint64_t step0, int32_t* ids, void* stream) {
+    DYN_REQUIRE(x && ids && rows >= 0 && C > 0 && ld >= C && inv_temperature > 0.f, DYN_E_ARG, "dyn_gumbel_argmax_rows: bad arguments");
+    if (rows == 0) return DYN_OK;
+    int64_t g = dyn::cdiv(rows, 4);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(gumbel_argmax_rows_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, ids, rows, (int)C, ld,
+                       inv_temperature, seed, step0);
+    return dyn::check_launch("dyn_gumbel_argmax_rows");
 }

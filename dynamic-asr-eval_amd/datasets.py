@@ -110,6 +110,36 @@ def proc_stm_lines(lines):
     return all_text, timings, remove_timings
 
 
+def fetch_utterances_from_lines(lines, waveform, sr=16000):
+    """STM lines + the talk's waveform [C, L] -> (utterance dicts, joined text): what reference wav2vec2/tedlium/run.py:56-83
+    (`fetch_utterances`) hands to `dynamic_eval_su` — scored segments only, sample range [int(start * sr), int(end * sr)) of the
+    waveform as a VIEW (no copy: the talk stays resident once), " 'x" glued back and spaces squeezed per utterance and again on
+    the joined text.  Pinned to the reference's own output (tests/golden/reference_pins.json: fetch_utterances)."""
+    import re
+
+    def tidy(t):
+        return re.sub(r" +", r" ", re.sub(r" '([a-z])", r"'\1", t))
+
+    utterances = []
+    for line in lines:
+        fields = line.split(' ')
+        if len(fields) < 6:
+            continue
+        text = ' '.join(fields[6:])
+        if text == 'ignore_time_segment_in_scoring':
+            continue
+        start, end = float(fields[3]), float(fields[4])
+        lo, hi = int(start * sr), int(end * sr)
+        utterances.append({'start': start, 'end': end, 'text': tidy(text), 'start_frame': lo, 'end_frame': hi, 'waveform': waveform[:, lo:hi]})
+    return utterances, tidy(" ".join(u['text'] for u in utterances))
+
+
+def fetch_utterances(stm_path, waveform, sr=16000):
+    """reference wav2vec2/tedlium/run.py:56-83 (same signature): reads the STM file, see fetch_utterances_from_lines."""
+    with open(stm_path, 'r') as f:
+        return fetch_utterances_from_lines(f.read().split('\n'), waveform, sr)
+
+
 def _process_tedlium(rec):
     """reference lcasr/tedlium/run.py:91-96: processing_chain(audio) then zero_out_spectogram(remove_timings)."""
     from .frontend import LogMel, zero_out_spectogram

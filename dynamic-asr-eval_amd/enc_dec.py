@@ -11,9 +11,12 @@ BUILD (parity unpinned, like the encoder's internals): token embedding + fixed s
 causal self-attention / cross-attention over the encoder states / SiLU FFN, final LayerNorm, linear head over the tokenizer
 vocabulary; bos = eos = 0 as in calc_loss_enc_dec's defaults (:1236-1237).  oracle/enc_dec_ref.py holds the same definition in torch.
 
-Scope: `training_mode == 'teacher_ce'` (:1638-1658).  The RL modes (`grpo`, `maxrl`: sampled rollouts, reward models) and the
-sampled-decode agreement filter are out of scope and raise.  Decoder parameters live in the encoder's flat buffers
-(SCConformerXL(extra_spec=...)), so snapshot / restore / MADGRAD step are the same single operations as on the CTC path."""
+Scope: `training_mode == 'teacher_ce'` (:1638-1658) with every flag of that path: the teacher filters incl. the sampled-decode
+agreement filter (`model.generate(sample=True, temperature=...)`, :1620-1627) and the decoder dropout knobs `dropout_emb /
+dropout_post_ff / dropout_attn` (:1511-1522,1636-1637,1703-1707).  Randomness is counter-based (dyn_dropout / dyn_gumbel_argmax_rows:
+a draw is a pure function of (seed, stream, index)), so it is reproducible and the oracle restates it exactly.  The RL modes
+(`grpo`, `maxrl`: sampled rollouts, reward models) are out of scope and raise.  Decoder parameters live in the encoder's flat
+buffers (SCConformerXL(extra_spec=...)), so snapshot / restore / MADGRAD step are the same single operations as on the CTC path."""
 import math
 import random
 from types import SimpleNamespace
@@ -70,6 +73,41 @@ class _NoParams:
         return []
 
 
+class _AttnFn:
+    """`layer[0].fn.dropout_p` of the reference's decoder layers (lib.py:1525,1636,1706): the self-attention dropout rate."""
+
+    def __init__(self):
+        self.dropout_p = 0.0
+
+
+class _DecoderKnobs:
+    """What the reference touches on `model.language_model_decoder`: `.pos_enc`, `.layers[i][0].fn.dropout_p`, `.dropout_emb`,
+    `.ff_out_dropout`, `.train()` / `.eval()` (dropout is applied in training mode only, as nn.Dropout)."""
+
+    def __init__(self, n_layers):
+        self.pos_enc = _NoParams()
+        self.layers = [[SimpleNamespace(fn=_AttnFn())] for _ in range(n_layers)]
+        self.dropout_emb = 0.0
+        self.ff_out_dropout = 0.0
+        self.training = False
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+
+def _check_ids(ids, vocab, what):
+    """Token ids are validated on the host before they reach the embedding / loss kernels (an id outside the decoder
+    vocabulary, e.g. a tokenizer / vocab_size mismatch, must fail loudly instead of reading out of bounds)."""
+    ids = [int(i) for i in ids]
+    if ids and (min(ids) < 0 or max(ids) >= vocab):
+        raise ops.DynError(f"{what}: token id outside [0, {vocab}) (min {min(ids)}, max {max(ids)}): tokenizer / vocab_size mismatch?")
+    return ids
+
+
 class EncDecSCConformerXL(SCConformerXL):
     """Encoder (this package's SCConformerXL, CTC head = `ctc_decoder`) + autoregressive decoder."""
 
@@ -84,11 +122,13 @@ class EncDecSCConformerXL(SCConformerXL):
         self.ctc_loss_weight = float(self.dec["ctc_loss_weight"])
         self.ctc_decoder = self.decoder                          # the reference's name for the CTC head (lib.py:1559)
         self.pos_table = sinusoidal_positions(self.dec["dec_max_positions"], self.dec["dec_d_model"]).to(self.device)
-        self.language_model_decoder = SimpleNamespace(pos_enc=_NoParams(), layers=[None] * self.dec["dec_layers"], dropout_emb=0.0,
-                                                      ff_out_dropout=0.0, train=lambda *a: None, eval=lambda *a: None)
+        # the attributes the reference's loop sets on `model.language_model_decoder` (lib.py:1519-1522,1636-1637,1703-1707)
+        self.language_model_decoder = _DecoderKnobs(self.dec["dec_layers"])
         self.pos_enc = _NoParams()
         self.use_graphs = False
         self._dctx = None
+        self.random_seed = 0          # seed of the counter-based dropout / sampling draws (args.random_seed in the loop)
+        self._draws = 0               # one stream id per random site and call: no draw is ever reused
 
     # ------------------------------------------------------------------ reference call surface
     def forward(self, audio_signal, text_sequence_bos=None, a_lengths=None):
@@ -104,34 +144,91 @@ class EncDecSCConformerXL(SCConformerXL):
 
     __call__ = forward
 
-    def generate(self, audio_signal, encoder_states=None, sample=False, temperature=1.0, max_tokens=None):
-        """Greedy autoregressive decode of ONE window -> {'text_sequence': [ids]} (reference call sites lib.py:1128,1579-1582).
-        The prefix is re-run through the decoder at every step (no KV cache yet); the cross-attention keys / values of the encoder
-        states are projected once."""
-        if sample:
-            raise NotImplementedError("sampled decoding (teacher_filter_decode_agreement / RL rollouts) is out of scope")
+    def generate(self, audio_signal, encoder_states=None, sample=False, temperature=1.0, max_tokens=None, seed=None, check_every=8):
+        """Autoregressive decode of ONE window -> {'text_sequence': [ids]} (reference call sites lib.py:1128,1579-1582,1620-1625):
+        greedy, or with `sample=True` a draw from softmax(logits / temperature) per step (Gumbel-max on counter-based uniforms:
+        dyn_gumbel_argmax_rows; `seed` defaults to a fresh stream of this model's random_seed).
+        Incremental: every step runs ONE token through the decoder against per-layer caches — the self-attention keys / values of
+        the prefix live in a packed [limit + 1, 3 * dd] buffer the QKV projection writes row t of, the cross-attention keys /
+        values of the encoder states are projected once.  The chosen id goes straight into the device token buffer; the host
+        looks for eos only every `check_every` steps (ids after the first eos are never read), so there is no per-token sync."""
         with torch.no_grad():
             enc = encoder_states if encoder_states is not None else self.forward(audio_signal)
             h = enc["hidden"][0]
             limit = max_tokens if max_tokens is not None else max(1, min(self.dec["dec_max_positions"] - 1, h.shape[0] // 2))
+            dc, P = self.dec, self.P
+            dd, L = dc["dec_d_model"], dc["dec_layers"]
+            if sample:
+                if not temperature > 0.0:
+                    raise ops.DynError("generate(sample=True): temperature must be > 0")
+                if seed is None:
+                    seed, step0 = self.random_seed, self._next_stream()
+                else:
+                    step0 = 0
+            st = torch.cuda.current_stream().cuda_stream
             with ops.use_workspace(self._scratch()):
-                kv = [ops.linear(h, self.P[f"{DEC}layers.{l}.cross.kv.weight"], self.P[f"{DEC}layers.{l}.cross.kv.bias"])
-                      for l in range(self.dec["dec_layers"])]
-                toks = [0]                                                    # bos
-                tok_dev = torch.zeros(limit + 1, dtype=torch.int32, device=self.device)
-                while len(toks) <= limit:
-                    logits = self._decoder_forward(tok_dev[:len(toks)], h, cached_kv=kv)
-                    ids, _ = ops.argmax_rows(logits[-1:])
-                    nxt = int(ids[0].item())
-                    if nxt == 0:                                              # eos
-                        break
-                    tok_dev[len(toks)] = nxt
-                    toks.append(nxt)
-        return {"text_sequence": toks[1:]}
+                kv = [ops.linear(h, P[f"{DEC}layers.{l}.cross.kv.weight"], P[f"{DEC}layers.{l}.cross.kv.bias"]) for l in range(L)]
+                cache = [torch.empty(limit + 1, 3 * dd, device=self.device, dtype=torch.float32) for _ in range(L)]
+                tok_dev = torch.zeros(limit + 2, dtype=torch.int32, device=self.device)           # tok_dev[0] = bos
+                n_tok, t = None, 0
+                while t < limit and n_tok is None:
+                    for _ in range(min(check_every, limit - t)):
+                        logits = self._decoder_step(tok_dev, t, h, kv, cache)                     # [1, V]
+                        nxt = tok_dev[t + 1:]
+                        if sample:
+                            check(load().dyn_gumbel_argmax_rows(logits.data_ptr(), 1, self.vocab, self.vocab, 1.0 / float(temperature), int(seed),
+                                                                int(step0 + t), nxt.data_ptr(), st), "dyn_gumbel_argmax_rows")
+                        else:
+                            check(load().dyn_argmax_rows(logits.data_ptr(), 1, self.vocab, self.vocab, nxt.data_ptr(), 0, st), "dyn_argmax_rows")
+                        t += 1
+                    got = tok_dev[1:t + 1].tolist()                                                # one sync per `check_every` tokens
+                    if 0 in got:                                                                   # eos
+                        n_tok = got.index(0)
+                toks = tok_dev[1:t + 1].tolist()[:n_tok] if n_tok is not None else tok_dev[1:t + 1].tolist()
+        return {"text_sequence": toks}
+
+    def _next_stream(self):
+        """A fresh block of 2^20 stream ids for one random site (dropout mask) or one sampled decode (one id per step)."""
+        self._draws += 1
+        return self._draws << 20
+
+    def _dropout(self, x, p, stream_id, out=None):
+        """y = dropout(x) with the mask of (random_seed, stream_id); the backward is the same call on the gradient."""
+        out = torch.empty_like(x) if out is None else out
+        check(load().dyn_dropout(x.data_ptr(), out.data_ptr(), x.numel(), float(p), int(self.random_seed), int(stream_id),
+                                 torch.cuda.current_stream().cuda_stream), "dyn_dropout")
+        return out
+
+    def _decoder_step(self, tok_dev, t, h_enc, kv, cache):
+        """One token (position t, id tok_dev[t]) through the decoder with cached keys / values -> logits [1, V]."""
+        P, dc = self.P, self.dec
+        dd, eps = dc["dec_d_model"], self.config["norm_eps"]
+        Tk = h_enc.shape[0]
+        st = torch.cuda.current_stream().cuda_stream
+        x = torch.empty(1, dd, device=self.device, dtype=torch.float32)
+        check(load().dyn_embedding_fwd(tok_dev[t:].data_ptr(), P[DEC + "embed.weight"].data_ptr(), self.pos_table[t:].data_ptr(), x.data_ptr(), 1, dd,
+                                       self.vocab, 1, st), "dyn_embedding_fwd")
+        for l in range(dc["dec_layers"]):
+            p = f"{DEC}layers.{l}."
+            c = cache[l]
+            n1, _, _ = ops.layernorm(x, P[p + "self.norm.weight"], P[p + "self.norm.bias"], eps)
+            row = ops.linear(n1, P[p + "self.qkv.weight"], P[p + "self.qkv.bias"], out=c[t:t + 1])          # q | k | v of position t
+            o1, _ = self._attend(row, c[:, dd:], c[:, 2 * dd:], 1, t + 1, 3 * dd, 3 * dd, False, False)        # the prefix IS the causal mask
+            x1 = ops.linear(o1, P[p + "self.out.weight"], P[p + "self.out.bias"], beta=1.0, residual=x)
+            n2, _, _ = ops.layernorm(x1, P[p + "cross.norm.weight"], P[p + "cross.norm.bias"], eps)
+            q2 = ops.linear(n2, P[p + "cross.q.weight"], P[p + "cross.q.bias"])
+            o2, _ = self._attend(q2, kv[l], kv[l][:, dd:], 1, Tk, dd, 2 * dd, False, False)
+            x2 = ops.linear(o2, P[p + "cross.out.weight"], P[p + "cross.out.bias"], beta=1.0, residual=x1)
+            n3, _, _ = ops.layernorm(x2, P[p + "ff.norm.weight"], P[p + "ff.norm.bias"], eps)
+            a = ops.silu(ops.linear(n3, P[p + "ff.w1.weight"]))
+            x = ops.linear(a, P[p + "ff.w2.weight"], beta=1.0, residual=x2)
+        nf, _, _ = ops.layernorm(x, P[DEC + "norm_out.weight"], P[DEC + "norm_out.bias"], eps)
+        return ops.linear(nf, P[DEC + "head.weight"], P[DEC + "head.bias"])
 
     # ------------------------------------------------------------------ decoder forward / backward (B = 1)
-    def _attend(self, q, k, v, S, Tk, ldq, ldk, causal, save):
-        """softmax(q k^T / sqrt(hd)) v per head; q rows have leading dimension ldq, k / v rows ldk (views into packed projections)."""
+    def _attend(self, q, k, v, S, Tk, ldq, ldk, causal, save, drop=None):
+        """softmax(q k^T / sqrt(hd)) v per head; q rows have leading dimension ldq, k / v rows ldk (views into packed projections).
+        `drop` = (p, stream id): dropout on the probabilities (training mode); returns (O, P[, dropped P])."""
         Hh, dd = self.dec["dec_heads"], self.dec["dec_d_model"]
         hd = dd // Hh
         Pm = torch.empty(Hh, S, Tk, device=self.device, dtype=torch.float32)
@@ -140,19 +237,25 @@ class EncDecSCConformerXL(SCConformerXL):
         if causal:
             check(load().dyn_causal_mask(Pm.data_ptr(), Hh, S, torch.cuda.current_stream().cuda_stream), "dyn_causal_mask")
         ops.softmax(Pm, out=Pm)
+        Pd = self._dropout(Pm, drop[0], drop[1]) if drop is not None else Pm
         O = torch.empty(S, dd, device=self.device, dtype=torch.float32)
-        ops.gemm(Pm, v, O, M=S, N=hd, K=Tk, lda=Tk, ldb=ldk, ldc=dd, nb1=1, nb2=Hh, sa=(0, S * Tk), sb=(0, hd), sc=(0, hd))
+        ops.gemm(Pd, v, O, M=S, N=hd, K=Tk, lda=Tk, ldb=ldk, ldc=dd, nb1=1, nb2=Hh, sa=(0, S * Tk), sb=(0, hd), sc=(0, hd))
+        if drop is not None:
+            return O, ((Pm, Pd) if save else None)
         return O, (Pm if save else None)
 
-    def _attend_bwd(self, dO, Pm, q, k, v, dq, dk, dv, S, Tk, ldq, ldk):
+    def _attend_bwd(self, dO, Pm, q, k, v, dq, dk, dv, S, Tk, ldq, ldk, drop=None):
         """Gradients of _attend into the (strided) dq / dk / dv views of the packed projection gradients; each view is written
-        exactly once (beta = 0)."""
+        exactly once (beta = 0).  With dropout `Pm` = (probabilities, dropped probabilities) and `drop` = (p, stream id)."""
         Hh, dd = self.dec["dec_heads"], self.dec["dec_d_model"]
         hd = dd // Hh
         sP = (0, S * Tk)
-        ops.gemm(Pm, dO, dv, trans_a=True, M=Tk, N=hd, K=S, lda=Tk, ldb=dd, ldc=ldk, nb1=1, nb2=Hh, sa=sP, sb=(0, hd), sc=(0, hd))
+        Pm, Pd = Pm if drop is not None else (Pm, Pm)
+        ops.gemm(Pd, dO, dv, trans_a=True, M=Tk, N=hd, K=S, lda=Tk, ldb=dd, ldc=ldk, nb1=1, nb2=Hh, sa=sP, sb=(0, hd), sc=(0, hd))
         dP = torch.empty_like(Pm)
         ops.gemm(dO, v, dP, trans_b=True, M=S, N=Tk, K=hd, lda=dd, ldb=ldk, ldc=Tk, nb1=1, nb2=Hh, sa=(0, hd), sb=(0, hd), sc=sP)
+        if drop is not None:
+            self._dropout(dP, drop[0], drop[1], out=dP)            # same mask, same 1 / (1 - p)
         ops.softmax_bwd(Pm, dP, out=dP, scale=1.0)
         sc = 1.0 / math.sqrt(hd)
         ops.gemm(dP, k, dq, M=S, N=hd, K=Tk, lda=Tk, ldb=ldk, ldc=ldq, nb1=1, nb2=Hh, sa=sP, sb=(0, hd), sc=(0, hd), alpha=sc)
@@ -171,12 +274,26 @@ class EncDecSCConformerXL(SCConformerXL):
         check(load().dyn_embedding_fwd(tokens.data_ptr(), P[DEC + "embed.weight"].data_ptr(), self.pos_table.data_ptr(), x.data_ptr(), S, dd,
                                        self.vocab, self.pos_table.shape[0], st), "dyn_embedding_fwd")
         ctx = {"tokens": tokens, "h_enc": h_enc, "layers": []} if save else None
+        # dropout: only in the decoder's training mode (the reference brackets the supervised step with .train() / .eval(),
+        # lib.py:1637,1703) and only for a forward that will be differentiated
+        knobs = self.language_model_decoder
+        train = save and knobs.training
+        p_emb = float(knobs.dropout_emb) if train else 0.0
+        p_ff = float(knobs.ff_out_dropout) if train else 0.0
+        d_emb = (p_emb, self._next_stream()) if p_emb > 0.0 else None
+        if d_emb is not None:
+            self._dropout(x, *d_emb, out=x)
+        if save:
+            ctx["d_emb"] = d_emb
         for l in range(dc["dec_layers"]):
             p = f"{DEC}layers.{l}."
             lc = {}
+            p_attn = float(knobs.layers[l][0].fn.dropout_p) if train else 0.0
+            d_attn = (p_attn, self._next_stream()) if p_attn > 0.0 else None
+            d_ff = (p_ff, self._next_stream()) if p_ff > 0.0 else None
             n1, m1, r1 = ops.layernorm(x, P[p + "self.norm.weight"], P[p + "self.norm.bias"], eps)
             qkv = ops.linear(n1, P[p + "self.qkv.weight"], P[p + "self.qkv.bias"])
-            o1, P1 = self._attend(qkv, qkv[:, dd:], qkv[:, 2 * dd:], S, S, 3 * dd, 3 * dd, True, save)
+            o1, P1 = self._attend(qkv, qkv[:, dd:], qkv[:, 2 * dd:], S, S, 3 * dd, 3 * dd, True, save, drop=d_attn)
             x1 = ops.linear(o1, P[p + "self.out.weight"], P[p + "self.out.bias"], beta=1.0, residual=x)
             n2, m2, r2 = ops.layernorm(x1, P[p + "cross.norm.weight"], P[p + "cross.norm.bias"], eps)
             q2 = ops.linear(n2, P[p + "cross.q.weight"], P[p + "cross.q.bias"])
@@ -186,10 +303,14 @@ class EncDecSCConformerXL(SCConformerXL):
             n3, m3, r3 = ops.layernorm(x2, P[p + "ff.norm.weight"], P[p + "ff.norm.bias"], eps)
             u = ops.linear(n3, P[p + "ff.w1.weight"])
             a = ops.silu(u)
-            x3 = ops.linear(a, P[p + "ff.w2.weight"], beta=1.0, residual=x2)
+            if d_ff is None:
+                x3 = ops.linear(a, P[p + "ff.w2.weight"], beta=1.0, residual=x2)
+            else:                                   # x3 = x2 + dropout(a W2^T)
+                x3 = self._dropout(ops.linear(a, P[p + "ff.w2.weight"]), *d_ff)
+                ops.axpby(x2, x3, a=1.0, b=1.0)
             if save:
                 lc = dict(x=x, n1=n1, m1=m1, r1=r1, qkv=qkv, P1=P1, o1=o1, x1=x1, n2=n2, m2=m2, r2=r2, q2=q2, kv=kv, P2=P2, o2=o2, x2=x2,
-                          n3=n3, m3=m3, r3=r3, u=u, a=a)
+                          n3=n3, m3=m3, r3=r3, u=u, a=a, d_attn=d_attn, d_ff=d_ff)
                 ctx["layers"].append(lc)
             x = x3
         nf, mf, rf = ops.layernorm(x, P[DEC + "norm_out.weight"], P[DEC + "norm_out.bias"], eps)
@@ -222,9 +343,10 @@ class EncDecSCConformerXL(SCConformerXL):
             p = f"{DEC}layers.{l}."
             c = ctx["layers"][l]
             # FFN
+            df = dx if c["d_ff"] is None else self._dropout(dx, *c["d_ff"])          # gradient of the (dropped) FFN branch; dx stays the residual's
             if self.trainable(p + "ff.w2.weight"):
-                ops.linear_wgrad(dx, c["a"], G[p + "ff.w2.weight"], beta=1.0)
-            du = ops.silu_bwd(c["u"], ops.linear_dgrad(dx, P[p + "ff.w2.weight"]))
+                ops.linear_wgrad(df, c["a"], G[p + "ff.w2.weight"], beta=1.0)
+            du = ops.silu_bwd(c["u"], ops.linear_dgrad(df, P[p + "ff.w2.weight"]))
             if self.trainable(p + "ff.w1.weight"):
                 ops.linear_wgrad(du, c["n3"], G[p + "ff.w1.weight"], beta=1.0)
             dn3 = ops.linear_dgrad(du, P[p + "ff.w1.weight"])
@@ -246,11 +368,14 @@ class EncDecSCConformerXL(SCConformerXL):
             do1 = ops.linear_dgrad(dx, P[p + "self.out.weight"])
             dqkv = torch.empty_like(c["qkv"])
             qkv = c["qkv"]
-            self._attend_bwd(do1, c["P1"], qkv, qkv[:, dd:], qkv[:, 2 * dd:], dqkv, dqkv[:, dd:], dqkv[:, 2 * dd:], S, S, 3 * dd, 3 * dd)
+            self._attend_bwd(do1, c["P1"], qkv, qkv[:, dd:], qkv[:, 2 * dd:], dqkv, dqkv[:, dd:], dqkv[:, 2 * dd:], S, S, 3 * dd, 3 * dd,
+                             drop=c["d_attn"])
             self._wb(dqkv, c["n1"], p + "self.qkv")
             dn1 = ops.linear_dgrad(dqkv, P[p + "self.qkv.weight"])
             ops.layernorm_bwd(c["x"], P[p + "self.norm.weight"], c["m1"], c["r1"], dn1, dx, G[p + "self.norm.weight"], G[p + "self.norm.bias"],
                               dx_beta=1.0)
+        if ctx["d_emb"] is not None:
+            self._dropout(dx, *ctx["d_emb"], out=dx)
         if self.trainable(DEC + "embed.weight"):
             check(load().dyn_embedding_bwd(tokens.data_ptr(), dx.data_ptr(), G[DEC + "embed.weight"].data_ptr(), S, dd, self.vocab, 1.0,
                                            torch.cuda.current_stream().cuda_stream), "dyn_embedding_bwd")
@@ -273,6 +398,7 @@ def calc_loss_enc_dec(model, audio_signal, text_sequence, a_lengths, t_lengths, 
     text = text_sequence.to(dev)
     assert text.shape[0] == 1 and audio_signal.shape[0] == 1, "calc_loss_enc_dec: batch of 1 (num_negatives == 1)"
     S = int(t_lengths[0])
+    _check_ids(text_sequence[0, :S].tolist(), model.vocab, "calc_loss_enc_dec: text_sequence")
     text_bos = torch.zeros(1, S + 1, dtype=torch.int32, device=dev)
     text_bos[:, 0] = bos_id
     text_bos[:, 1:] = text[:, :S].to(torch.int32)
@@ -314,7 +440,8 @@ def calc_loss_enc_dec(model, audio_signal, text_sequence, a_lengths, t_lengths, 
 
 
 def generate_enc_dec(model, audio_signal, **kw):
-    """reference call site lib.py:1128: `generate_enc_dec(model, audio_chunk)[0]` -> token ids of the greedy decode."""
+    """reference call site lib.py:1128: `generate_enc_dec(model, audio_chunk)[0]` -> token ids of the greedy decode.  The
+    `sample=4, greedy=False` form is the RL rollout of the grpo / maxrl modes (lib.py:1667-1673): out of scope."""
     if kw.get("sample", 1) != 1 or kw.get("greedy", True) is False:
         raise NotImplementedError("sampled rollouts (RL modes) are out of scope")
     return [torch.tensor(model.generate(audio_signal)["text_sequence"], dtype=torch.long)]
@@ -346,11 +473,19 @@ def enc_dec_dynamic_eval(args, model, spec, seq_len, overlap, tokenizer, use_tqd
     mode = getattr(args, 'training_mode', 'grpo')
     if mode != 'teacher_ce':
         raise NotImplementedError(f"training_mode {mode!r}: only 'teacher_ce' is implemented (the RL modes grpo / maxrl are out of scope)")
-    if args.__dict__.get('teacher_filter_decode_agreement', False):
-        raise NotImplementedError("teacher_filter_decode_agreement needs sampled decoding (out of scope)")
-    for k in ('dropout_emb', 'dropout_post_ff', 'dropout_attn'):
-        if args.__dict__.get(k, 0.0) != 0.0:
-            raise NotImplementedError(f"{k} > 0: decoder dropout is not implemented")
+    dropout_emb = args.__dict__.get('dropout_emb', 0.0)
+    dropout_post_ff = args.__dict__.get('dropout_post_ff', 0.0)
+    dropout_attn = args.__dict__.get('dropout_attn', 0.0)
+    for k, v in (('dropout_emb', dropout_emb), ('dropout_post_ff', dropout_post_ff), ('dropout_attn', dropout_attn)):
+        if not 0.0 <= float(v) < 1.0:
+            raise ValueError(f"{k} must be in [0, 1), got {v}")
+    # the reference's knobs on the decoder (lib.py:1519-1525): embedding / post-FFN dropout for the whole call, attention dropout
+    # only around the supervised step; draws are counter-based and restart with every call (reproducible: `random_seed`)
+    model.language_model_decoder.dropout_emb = dropout_emb
+    model.language_model_decoder.ff_out_dropout = dropout_post_ff
+    for layer in model.language_model_decoder.layers:
+        layer[0].fn.dropout_p = 0
+    model.random_seed, model._draws = int(args.__dict__.get('random_seed', 0)), 0
     spec_augment_config = get_specaugment_config_from_args(args)
     print(spec_augment_config)
     lr_args = get_lr_args_from_args(args)
@@ -393,12 +528,13 @@ def enc_dec_dynamic_eval(args, model, spec, seq_len, overlap, tokenizer, use_tqd
                     augmentation.apply(audio_chunk[b], masks, _window_fill_value(audio_chunk[b], augmentation.zero_masking))
             with torch.no_grad():
                 encoder_out_for_teacher = model.forward(audio_signal=audio_chunk[-1:].contiguous())
-            teacher_pred_tokens = model.generate(audio_chunk[-1:], encoder_states=encoder_out_for_teacher)["text_sequence"]
+            teacher_pred_tokens = _check_ids(model.generate(audio_chunk[-1:], encoder_states=encoder_out_for_teacher)["text_sequence"],
+                                             model.vocab, "teacher prediction")
             teacher_pred = torch.tensor(teacher_pred_tokens, dtype=torch.long, device=device)
             teacher_pred_text = tokenizer.decode(teacher_pred_tokens).strip()
             text_lengths = torch.LongTensor([teacher_pred.shape[-1]])
             acoustic_length = torch.LongTensor([audio_chunk.shape[-1]])
-            teacher_mean_max_prob, teacher_mean_entropy, ctc_text = None, None, None
+            teacher_mean_max_prob, teacher_mean_entropy, ctc_text, agreement_text = None, None, None, None
             if args.__dict__.get('teacher_filter_low_confidence', False) or args.__dict__.get('teacher_filter_ctc_agreement', False):
                 teacher_inputs = torch.zeros(1, teacher_pred.shape[-1] + 1, dtype=torch.int32, device=device)
                 teacher_inputs[:, 1:] = teacher_pred.to(torch.int32)
@@ -412,18 +548,28 @@ def enc_dec_dynamic_eval(args, model, spec, seq_len, overlap, tokenizer, use_tqd
                     teacher_mean_entropy = float(ent.mean().item())
                 if args.__dict__.get('teacher_filter_ctc_agreement', False) and ctc_decoder is not None:
                     ctc_text = ctc_decoder(tf['final_posteriors_ctc'][0]).strip()
+            if args.__dict__.get('teacher_filter_decode_agreement', False):             # lib.py:1620-1627: a second, SAMPLED decode
+                agreement_gen = model.generate(audio_chunk[-1:], encoder_states=encoder_out_for_teacher, sample=True,
+                                               temperature=args.__dict__.get('teacher_decode_agreement_temperature', 0.7))
+                agreement_text = tokenizer.decode(agreement_gen["text_sequence"]).strip()
             print(f'Teacher pred: {teacher_pred_text}')
             skip, reason = should_skip_faulty_teacher_prediction(
                 args=args, teacher_pred_tokens=teacher_pred_tokens, teacher_pred_text=teacher_pred_text, spec_frames=audio_chunk.shape[-1],
-                agreement_text=None, teacher_mean_max_prob=teacher_mean_max_prob, teacher_mean_entropy=teacher_mean_entropy, ctc_text=ctc_text)
+                agreement_text=agreement_text, teacher_mean_max_prob=teacher_mean_max_prob, teacher_mean_entropy=teacher_mean_entropy, ctc_text=ctc_text)
             if skip:
                 print(f'Skipping teacher update: {reason}')
                 continue
+            for layer in model.language_model_decoder.layers:                            # lib.py:1636-1637
+                layer[0].fn.dropout_p = dropout_attn
+            model.language_model_decoder.train()   # for dropout
             optimizer.zero_grad()
             out = calc_loss_enc_dec(model=model, audio_signal=audio_chunk[:num_negatives].contiguous(), text_sequence=teacher_pred[None, :],
                                     a_lengths=acoustic_length, t_lengths=text_lengths, tokenizer=tokenizer)
             print(out['loss'], "loss (teacher_ce)")
             optimizer.step()
+            model.language_model_decoder.eval()                                          # lib.py:1703-1707
+            for layer in model.language_model_decoder.layers:
+                layer[0].fn.dropout_p = 0
     model.eval()
     final_out = enc_dec_inference(model=model, spec=spec, seq_len=seq_len, overlap=overlap, tokenizer=tokenizer, use_tqdm=use_tqdm)
     if return_params:

@@ -18,23 +18,41 @@ import time
 import torch
 
 from . import wav2vec2_lib as lib
-from .datasets import synthetic_text, synthetic_waveform
+from .datasets import fetch_utterances_from_lines, synthetic_text, synthetic_waveform
 from .decoding import GreedyCTCDecoder
 from .wav2vec2_model import Wav2Vec2ForCTC
 from .wer import basic_normalize as normalize, word_error_rate_detail
 
 
-def fetch_utterances_synthetic(total_seconds=900.0, seed=7, sample_rate=16000):
-    """Utterance list like reference wav2vec2/tedlium/run.py:56-83 produces: dicts with 'waveform' [1, L] and 'text'."""
+def synthetic_talk(total_seconds=900.0, seed=7, sample_rate=16000):
+    """A TEDLIUM-shape talk: STM lines (utterances of 2-15 s, every 9th segment `ignore_time_segment_in_scoring`) and ONE waveform
+    [1, L] for the whole talk, resident once; the utterances are cut out of it by the reference's own rule below."""
     g = torch.Generator().manual_seed(seed)
-    utts, t = [], 0.0
+    lines, t, k = [], 0.0, 0
     while t < total_seconds:
         d = float(2.0 + 13.0 * torch.rand(1, generator=g).item())
         d = min(d, total_seconds - t) if total_seconds - t > 2.0 else d
-        wav = synthetic_waveform(d, seed=seed + len(utts), sample_rate=sample_rate)
-        text = " ".join(w.replace("w", "word") for w in synthetic_text(max(1, int(2.5 * d)), seed + len(utts)).split())
-        utts.append({'waveform': wav.unsqueeze(0), 'text': text, 'start': t, 'end': t + d})
-        t += d
+        if k % 9 == 8:
+            text = "ignore_time_segment_in_scoring"
+        else:
+            text = " ".join(w.replace("w", "word") for w in synthetic_text(max(1, int(2.5 * d)), seed + k).split())
+        lines.append(f"talk{seed} 1 spk{seed} {t:.2f} {t + d:.2f} <o,f0,unknown> {text}")
+        t, k = t + d, k + 1
+    return lines, synthetic_waveform(t, seed=seed, sample_rate=sample_rate).unsqueeze(0)
+
+
+def fetch_utterances_synthetic(total_seconds=900.0, seed=7, sample_rate=16000, stm_path=None):
+    """Utterance list exactly as reference wav2vec2/tedlium/run.py:56-83 builds it (datasets.fetch_utterances, pinned to the
+    reference's output): from `stm_path` when given (the audio itself cannot be decoded offline: a synthetic waveform of the STM's
+    span stands in), else from a synthetic talk."""
+    if stm_path:
+        with open(stm_path, 'r') as f:
+            lines = f.read().split('\n')
+        ends = [float(l.split(' ')[4]) for l in lines if len(l.split(' ')) >= 6]
+        wave = synthetic_waveform(max(ends) + 1.0, seed=seed, sample_rate=sample_rate).unsqueeze(0)
+    else:
+        lines, wave = synthetic_talk(total_seconds, seed, sample_rate)
+    utts, _ = fetch_utterances_from_lines(lines, wave, sample_rate)
     return utts
 
 
@@ -71,7 +89,7 @@ def main(args):
     model.eval()
     tokenizer.blank_id = 0
     decoder = GreedyCTCDecoder(tokenizer=tokenizer, blank_id=tokenizer.blank_id, device=device)
-    utterances = fetch_utterances_synthetic(args.seconds, args.seed + (0 if args.split == 'test' else 1000))
+    utterances = fetch_utterances_synthetic(args.seconds, args.seed + (0 if args.split == 'test' else 1000), stm_path=args.stm or None)
     gold_text = normalize(" ".join(u['text'] for u in utterances)).lower()
     all_texts, all_golds = [], []
     torch.cuda.synchronize()
@@ -99,7 +117,8 @@ def main(args):
     if args.log != '':
         with open(args.log, 'a') as f:
             f.write(f'{args.checkpoint}\t overlap: {args.overlap}\t seq_len: {args.seq_len}\t WER: {wer}\n')
-    print(f'wav2vec2 {args.mode}: {len(utterances)} utterances, {args.seconds:.0f} s of audio in {dt:.2f} s -> {args.seconds / dt:.1f} audio-s/s')
+    audio_s = sum(u['waveform'].shape[-1] for u in utterances) / 16000.0
+    print(f'wav2vec2 {args.mode}: {len(utterances)} utterances, {audio_s:.0f} s of audio in {dt:.2f} s -> {audio_s / dt:.1f} audio-s/s')
     return wer
 
 
@@ -109,6 +128,7 @@ def build_parser():
     ap.add_argument('--seconds', type=float, default=900.0)
     ap.add_argument('--lr', type=float, default=1e-6)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--stm', type=str, default='', help='TEDLIUM .stm file: its segments define the utterances (reference tedlium/run.py:56-83)')
     return ap
 
 

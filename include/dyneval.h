@@ -280,6 +280,17 @@ int dyn_embedding_bwd(const int32_t* ids, const float* dy, float* dtable, int64_
 int dyn_causal_mask(float* scores, int64_t nb, int64_t S, void* stream);
 int dyn_nll_loss(const float* log_probs, const int32_t* targets, float* loss, float* row_loss, float* grad, int64_t rows, int64_t C,
                  int32_t ignore_index, float grad_scale, void* stream);
+/* Counter-based randomness of the teacher_ce path (no device RNG state, a draw is a pure function of (seed, stream, index)):
+ *   z = splitmix64_finish(seed ^ (stream + 1) * 0x9E3779B97F4A7C15 ^ (index + 1) * 0xC2B2AE3D27D4EB4F)
+ *   dropout:  keep element i iff (z >> 40) * 2^-24 >= p;  y = keep ? x * 1 / (1 - p) : 0   (in place allowed; the backward is the same
+ *             call on the gradient).  Replaces nn.Dropout of `language_model_decoder.dropout_emb / ff_out_dropout` and the attention
+ *             `dropout_p` the reference switches on around the supervised step (lcasr/lib.py:1511-1522,1636-1637,1703-1707).
+ *   sampling: ids[r] = argmax_c (x[r, c] * inv_temperature + g), g = -log(-log(u)), u = (2 * (z >> 41) + 1) * 2^-24 with
+ *             stream = step0 + r, index = c  (Gumbel-max = a draw from softmax(x / temperature)): `model.generate(sample=True,
+ *             temperature=...)` of the decode-agreement filter (lcasr/lib.py:1620-1627). */
+int dyn_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
+int dyn_gumbel_argmax_rows(const float* x, int64_t rows, int64_t C, int64_t ld, float inv_temperature, uint64_t seed, uint64_t step0,
+                           int32_t* ids, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CTC.  dyn_ctc_greedy replaces GreedyCTCDecoder on a CPU copy of the posteriors (reference lcasr/lib.py:498,

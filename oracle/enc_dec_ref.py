@@ -28,6 +28,50 @@ def sinusoidal_positions(n, d):
     return tab.float()
 
 
+# ---- counter-based randomness, restated from include/dyneval.h (dyn_dropout / dyn_gumbel_argmax_rows): a draw is a pure function
+# of (seed, stream, index), so the oracle reproduces the product's masks and samples exactly
+import numpy as np
+
+_M64 = (1 << 64) - 1
+
+
+def mix64(seed, stream, index):
+    """index: numpy uint64 array -> numpy uint64 array (splitmix64 finaliser over seed ^ stream / index multiples)."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & _M64) ^ np.uint64(((stream + 1) * 0x9E3779B97F4A7C15) & _M64) ^ ((index + np.uint64(1)) * np.uint64(0xC2B2AE3D27D4EB4F))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def dropout_mask(shape, p, seed, stream):
+    """keep-and-scale factors (0 or 1 / (1 - p) in fp32) of dyn_dropout for a contiguous tensor of `shape`."""
+    n = int(np.prod(shape))
+    u = (mix64(seed, stream, np.arange(n, dtype=np.uint64)) >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return torch.from_numpy(np.where(u >= np.float32(p), scale, np.float32(0.0)).astype(np.float32)).reshape(shape)
+
+
+def gumbel_argmax(logits, temperature, seed, step):
+    """dyn_gumbel_argmax_rows for one row: argmax_c (x_c / T + g_c), g = -log(-log(u)), u = (2 (z >> 41) + 1) 2^-24."""
+    C = logits.shape[-1]
+    u = (np.float64(2.0) * (mix64(seed, step, np.arange(C, dtype=np.uint64)) >> np.uint64(41)).astype(np.float64) + 1.0) * 2.0 ** -24
+    g = -np.log(-np.log(u))
+    inv_t = np.float32(1.0) / np.float32(temperature)
+    return int(np.argmax(logits.detach().numpy().astype(np.float64) * np.float64(inv_t) + g))
+
+
+class _Streams:
+    """The product's stream-id allocator (enc_dec.py `_next_stream`): one block of 2^20 ids per random site / sampled decode."""
+
+    def __init__(self):
+        self.draws = 0
+
+    def next(self):
+        self.draws += 1
+        return self.draws << 20
+
+
 class _Attn(nn.Module):
     def __init__(self, dd, d_kv, heads, cross):
         super().__init__()
@@ -39,7 +83,7 @@ class _Attn(nn.Module):
             self.qkv = _Lin(dd, 3 * dd)
         self.out = _Lin(dd, dd)
 
-    def forward(self, x, mem=None):
+    def forward(self, x, mem=None, drop=None):
         S, dd = x.shape
         H = self.heads
         n = self.norm(x)
@@ -52,7 +96,10 @@ class _Attn(nn.Module):
         sc = q @ k.transpose(-1, -2) / math.sqrt(dd // H)
         if not self.cross:
             sc = sc.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
-        o = (torch.softmax(sc, -1) @ v).transpose(0, 1).reshape(S, dd)
+        pm = torch.softmax(sc, -1)
+        if drop is not None:                                     # (p, seed, stream): dropout on the probabilities [H, S, S]
+            pm = pm * dropout_mask(pm.shape, *drop)
+        o = (pm @ v).transpose(0, 1).reshape(S, dd)
         return x + self.out(o)
 
 
@@ -62,8 +109,11 @@ class _FF(nn.Module):
         self.norm = _Norm(dd, "layer_norm")
         self.w1, self.w2 = _Lin(dd, dd * mult, bias=False), _Lin(dd * mult, dd, bias=False)
 
-    def forward(self, x):
-        return x + self.w2(F.silu(self.w1(self.norm(x))))
+    def forward(self, x, drop=None):
+        f = self.w2(F.silu(self.w1(self.norm(x))))
+        if drop is not None:
+            f = f * dropout_mask(f.shape, *drop)
+        return x + f
 
 
 class _DecLayer(nn.Module):
@@ -90,11 +140,20 @@ class Decoder(nn.Module):
         self.norm_out = _Norm(dd, "layer_norm")
         self.head = _Lin(dd, vocab)
         self.register_buffer("pos", sinusoidal_positions(dc["dec_max_positions"], dd), persistent=False)
+        # the knobs the reference's loop sets (lib.py:1519-1525,1636-1637,1703-1707); dropout only in training mode
+        self.dropout_emb, self.ff_out_dropout, self.dropout_attn = 0.0, 0.0, 0.0
+        self.random_seed, self.streams = 0, _Streams()
 
     def forward(self, tokens, mem):
         x = self.embed.weight[tokens] + self.pos[:tokens.shape[0]]
+        train = self.training and torch.is_grad_enabled()
+        seed = self.random_seed
+        if train and self.dropout_emb > 0:                      # stream ids in the product's order: embedding, then per layer attention, FFN
+            x = x * dropout_mask(x.shape, self.dropout_emb, seed, self.streams.next())
         for l in self.layers:
-            x = l.ff(l.cross(l.self(x), mem))
+            d_attn = (self.dropout_attn, seed, self.streams.next()) if train and self.dropout_attn > 0 else None
+            d_ff = (self.ff_out_dropout, seed, self.streams.next()) if train and self.ff_out_dropout > 0 else None
+            x = l.ff(l.cross(l.self(x, drop=d_attn), mem), drop=d_ff)
         return self.head(self.norm_out(x))
 
 
@@ -136,14 +195,20 @@ class EncDecRef(nn.Module):
         return out
 
     @torch.no_grad()
-    def generate(self, audio_signal, encoder_states=None, max_tokens=None):
+    def generate(self, audio_signal, encoder_states=None, max_tokens=None, sample=False, temperature=1.0, seed=None):
         enc = encoder_states if encoder_states is not None else self.forward(audio_signal)
         h = enc["hidden"][0]
         limit = max_tokens if max_tokens is not None else max(1, min(self.dec["dec_max_positions"] - 1, h.shape[0] // 2))
+        dec = self.language_model_decoder
+        if sample:
+            seed, step0 = (dec.random_seed, dec.streams.next()) if seed is None else (seed, 0)
         toks = [0]
         while len(toks) <= limit:
-            logits = self.language_model_decoder(torch.LongTensor(toks), h)
-            nxt = int(torch.argmax(logits[-1]).item())
+            logits = dec(torch.LongTensor(toks), h)
+            if sample:
+                nxt = gumbel_argmax(logits[-1], temperature, seed, step0 + len(toks) - 1)
+            else:
+                nxt = int(torch.argmax(logits[-1]).item())
             if nxt == 0:
                 break
             toks.append(nxt)
@@ -184,9 +249,15 @@ def enc_dec_inference_ref(model, spec, seq_len, overlap, tokenizer):
 
 
 def enc_dec_dynamic_eval_ref(model, spec, seq_len, tokenizer, optimizer_cls, lr_args, epochs=1, fixed_masks=None, return_params=False,
-                             skip_fn=None):
-    """reference lcasr/lib.py:1475-1732, training_mode 'teacher_ce', filters applied through `skip_fn(tokens, text, frames)`."""
+                             skip_fn=None, dropout_emb=0.0, dropout_post_ff=0.0, dropout_attn=0.0, agreement_temperature=None,
+                             random_seed=0, trace=None):
+    """reference lcasr/lib.py:1475-1732, training_mode 'teacher_ce', filters applied through `skip_fn(tokens, text, frames[,
+    agreement_text])`; `agreement_temperature` switches the sampled second decode of the decode-agreement filter on (:1620-1627);
+    the three dropout knobs as the reference sets them (:1511-1525,1636-1637,1703-1707).  `trace` collects (teacher, agreement) texts."""
     spec_n = spec.shape[-1]
+    dec = model.language_model_decoder
+    dec.dropout_emb, dec.ff_out_dropout, dec.dropout_attn = dropout_emb, dropout_post_ff, 0.0
+    dec.random_seed, dec.streams = random_seed, _Streams()
     original = [p.clone().detach() for p in model.ordered_parameters()]
     optimizer = optimizer_cls(model.ordered_parameters(), **lr_args)
     overlap = 0
@@ -205,13 +276,26 @@ def enc_dec_dynamic_eval_ref(model, spec, seq_len, tokenizer, optimizer_cls, lr_
             teacher_tokens = model.generate(audio_chunk[-1, None], encoder_states=enc_states)["text_sequence"]
             teacher_pred = torch.tensor(teacher_tokens, dtype=torch.long)
             teacher_text = tokenizer.decode(teacher_tokens).strip()
-            if skip_fn is not None and skip_fn(teacher_tokens, teacher_text, audio_chunk.shape[-1]):
-                continue
+            agreement_text = None
+            if agreement_temperature is not None:
+                agreement_text = tokenizer.decode(model.generate(audio_chunk[-1, None], encoder_states=enc_states, sample=True,
+                                                                 temperature=agreement_temperature)["text_sequence"]).strip()
+            if trace is not None:
+                trace.append((teacher_text, agreement_text))
+            if skip_fn is not None:
+                skip = skip_fn(teacher_tokens, teacher_text, audio_chunk.shape[-1], agreement_text) if agreement_temperature is not None \
+                    else skip_fn(teacher_tokens, teacher_text, audio_chunk.shape[-1])
+                if skip:
+                    continue
+            dec.dropout_attn = dropout_attn
+            dec.train()
             loss = calc_loss_enc_dec_ref(model, audio_chunk[:1], teacher_pred[None, :], torch.LongTensor([audio_chunk.shape[-1]]),
                                          torch.LongTensor([teacher_pred.shape[-1]]))
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()
+            dec.eval()
+            dec.dropout_attn = 0.0
     model.eval()
     final_out = enc_dec_inference_ref(model, spec, seq_len, overlap, tokenizer)
     updated = [p.clone().detach() for p in model.ordered_parameters()] if return_params else None

@@ -15,6 +15,7 @@ nothing but `torch`, `re`, `random` and `typing.List` in their namespace — no 
                           tail window                         -> stitch_inner_*
   lcasr/run_seq_eval.py:130-144  the outer stitch statements  -> stitch_outer_*
   lcasr/tedlium/run.py:25-51     open_stm + proc_stm_and_timings on a synthetic STM file -> json
+  wav2vec2/tedlium/run.py:25-83  open_stm + fetch_utterances on the same STM lines and a ramp waveform -> json (fetch_utterances)
   wav2vec2/soft_dtw_cuda.py:319-329  SoftDTW._euclidean_dist_func -> sqdist_*
   lcasr/enc_dec_teacher_filters.py   add_enc_dec_teacher_filter_args defaults + should_skip_faulty_teacher_prediction decisions -> json
 """
@@ -156,6 +157,20 @@ def main():
     text, timings, remove = ns["proc_stm_and_timings"](path)
     os.unlink(path)
     meta["stm"] = {"lines": stm_lines, "text": text, "timings": timings, "remove_timings": remove}
+
+    # ---- wav2vec2 per-utterance slicing (wav2vec2/tedlium/run.py:56-83): STM lines -> utterance dicts with waveform views
+    ns = ref_functions("wav2vec2/tedlium/run.py", ["open_stm", "fetch_utterances"], base)
+    sr = 16000
+    wave = torch.arange(34 * sr, dtype=torch.float32)[None] * 0.5            # a ramp: every slice is identified by its first / last value
+    with tempfile.NamedTemporaryFile("w", suffix=".stm", delete=False) as f:
+        f.write("\n".join(stm_lines))
+        path = f.name
+    utts, all_text = ns["fetch_utterances"](path, wave, sr)
+    os.unlink(path)
+    meta["fetch_utterances"] = {"sample_rate": sr, "wave_samples": int(wave.shape[1]), "wave_rule": "0.5 * arange", "all_text": all_text,
+                                "utterances": [{"start": u["start"], "end": u["end"], "text": u["text"], "start_frame": u["start_frame"],
+                                                "end_frame": u["end_frame"], "shape": list(u["waveform"].shape),
+                                                "first": float(u["waveform"][0, 0]), "last": float(u["waveform"][0, -1])} for u in utts]}
 
     # ---- squared Euclidean distance of the soft-DTW module (wav2vec2/soft_dtw_cuda.py:319-329)
     ns = ref_functions("wav2vec2/soft_dtw_cuda.py", ["_euclidean_dist_func"], base)

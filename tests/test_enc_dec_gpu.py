@@ -106,6 +106,131 @@ def test_enc_dec_dynamic_eval_teacher_ce_matches_oracle(cuda, filters):
         enc_dec_dynamic_eval(args, hip, spec, 256, 0, tok, use_tqdm=False)
 
 
+def test_counter_based_dropout_and_sampling_kernels_match_their_restatement(cuda):
+    """dyn_dropout / dyn_gumbel_argmax_rows (include/dyneval.h) against oracle/enc_dec_ref.py's numpy restatement of the same
+    counter-based draws: masks bit-exact, sampled ids equal, and the sample frequencies follow softmax(x / T)."""
+    from oracle.enc_dec_ref import dropout_mask, gumbel_argmax
+    from dynamic_asr_eval_amd._lib import check, load
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(7, 333, generator=torch.Generator().manual_seed(1))
+    for p, seed, stream in ((0.1, 0, 1 << 20), (0.5, 12345, (3 << 20) + 7), (0.0, 9, 2)):
+        y = torch.empty_like(x, device=cuda)
+        xd = x.to(cuda)
+        check(load().dyn_dropout(xd.data_ptr(), y.data_ptr(), x.numel(), p, seed, stream, st), "dyn_dropout")
+        assert torch.equal(y.cpu(), x * dropout_mask(x.shape, p, seed, stream)), (p, seed, stream)
+    logits = torch.randn(50, 64, generator=torch.Generator().manual_seed(2)) * 2
+    ids = torch.empty(50, dtype=torch.int32, device=cuda)
+    ld = logits.to(cuda)
+    check(load().dyn_gumbel_argmax_rows(ld.data_ptr(), 50, 64, 64, 1.0 / 0.7, 77, 1 << 20, ids.data_ptr(), st), "dyn_gumbel_argmax_rows")
+    want = [gumbel_argmax(logits[r], 0.7, 77, (1 << 20) + r) for r in range(50)]
+    assert ids.cpu().tolist() == want
+    # distribution: 20000 draws of one row at T = 1.3
+    row = torch.tensor([2.0, 1.0, 0.0, -1.0, 0.5, 1.5, -0.5, 0.2])
+    many = row[None].repeat(20000, 1).contiguous().to(cuda)
+    ids = torch.empty(20000, dtype=torch.int32, device=cuda)
+    check(load().dyn_gumbel_argmax_rows(many.data_ptr(), 20000, 8, 8, 1.0 / 1.3, 5, 0, ids.data_ptr(), st), "dyn_gumbel_argmax_rows")
+    freq = torch.bincount(ids.cpu().long(), minlength=8).float() / 20000
+    assert (freq - torch.softmax(row / 1.3, -1)).abs().max().item() < 0.015, freq
+
+
+def test_generate_with_kv_cache_greedy_and_sampled_matches_oracle(cuda):
+    """`model.generate` (reference call sites lib.py:1128,1580,1620-1625): the incremental KV-cache decode equals the oracle's
+    prefix re-run token for token — greedy, and sampled at temperature 0.7 / 1.5 with the shared counter-based draws; the host
+    only looks for eos every `check_every` tokens, which must not change the result."""
+    ref, hip = _pair(cuda, seed=5)
+    x = torch.randn(1, 80, 480, generator=torch.Generator().manual_seed(8))
+    want = ref.generate(x)["text_sequence"]
+    for every in (1, 3, 8, 64):
+        assert hip.generate(x.to(cuda), check_every=every)["text_sequence"] == want
+    assert len(want) >= 3
+    for temp, seed in ((0.7, 11), (1.5, 12)):
+        w = ref.generate(x, sample=True, temperature=temp, seed=seed)["text_sequence"]
+        g = hip.generate(x.to(cuda), sample=True, temperature=temp, seed=seed)["text_sequence"]
+        assert g == w, (temp, g, w)
+    assert ref.generate(x, sample=True, temperature=1.5, seed=12)["text_sequence"] != want     # the sampled decode really differs
+    short = hip.generate(x.to(cuda), max_tokens=2)["text_sequence"]
+    assert short == want[:2]
+
+
+def test_decoder_dropout_forward_and_every_gradient(cuda):
+    """The three decoder dropout knobs (`dropout_emb`, `dropout_post_ff` -> ff_out_dropout, `dropout_attn` -> layer[0].fn.dropout_p;
+    reference lcasr/lib.py:1511-1525,1636-1637) in training mode: loss and every gradient vs autograd with the same masks; in eval
+    mode the knobs are inert."""
+    from oracle.enc_dec_ref import _Streams, calc_loss_enc_dec_ref
+    from dynamic_asr_eval_amd.enc_dec import calc_loss_enc_dec
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    ref, hip = _pair(cuda)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 80, 400, generator=g)
+    text = torch.randint(1, VOCAB, (1, 11), generator=g)
+    a_len, t_len = torch.LongTensor([400]), torch.LongTensor([11])
+    tok = SyntheticTokenizer(VOCAB)
+    plain = calc_loss_enc_dec(hip, x.to(cuda), text, a_len, t_len, tok, backward=False)["loss"]
+    dec = ref.language_model_decoder
+    dec.dropout_emb, dec.ff_out_dropout, dec.dropout_attn, dec.random_seed, dec.streams = 0.1, 0.2, 0.15, 42, _Streams()
+    knobs = hip.language_model_decoder
+    knobs.dropout_emb, knobs.ff_out_dropout = 0.1, 0.2
+    for layer in knobs.layers:
+        layer[0].fn.dropout_p = 0.15
+    hip.random_seed, hip._draws = 42, 0
+    assert calc_loss_enc_dec(hip, x.to(cuda), text, a_len, t_len, tok, backward=False)["loss"] == plain       # eval mode: inert
+    assert hip._draws == 0
+    dec.train(); knobs.train()
+    loss_ref = calc_loss_enc_dec_ref(ref, x, text, a_len, t_len)
+    loss_ref.backward()
+    hip.zero_grad()
+    out = calc_loss_enc_dec(hip, x.to(cuda), text, a_len, t_len, tok)
+    dec.eval(); knobs.eval()
+    assert hip._draws == dec.streams.draws == 1 + 2 * CFG["dec_layers"]
+    assert abs(out["loss"] - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref))) and abs(out["loss"] - plain) > 1e-3
+    for (n, _), gh, p in zip(hip.named_parameters(), hip.grads(), ref.ordered_parameters()):
+        rel = (gh.cpu() - p.grad).abs().max().item() / (p.grad.abs().max().item() + 1e-12)
+        assert rel < 2e-3, (n, rel)
+
+
+def test_enc_dec_dynamic_eval_with_decode_agreement_and_dropout_matches_oracle(cuda):
+    """The loop with `teacher_filter_decode_agreement` (a second, sampled decode per window, lib.py:1620-1627; the CER-similarity
+    decision of enc_dec_teacher_filters.py is pinned to the reference) and the three dropout knobs on: same teacher / agreement
+    texts, same skip decisions, same adapted parameters and final transcript as the oracle loop."""
+    from oracle import dynamic_eval_ref as R
+    from oracle.enc_dec_ref import enc_dec_dynamic_eval_ref
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd.enc_dec import enc_dec_dynamic_eval
+    from dynamic_asr_eval_amd.enc_dec_teacher_filters import add_enc_dec_teacher_filter_args, should_skip_faulty_teacher_prediction
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    ref, hip = _pair(cuda, seed=7)
+    tok = SyntheticTokenizer(VOCAB)
+    spec = torch.randn(1, 80, 1000, generator=torch.Generator().manual_seed(4))
+    _, keys = R.prepare_chunks(spec, 256, 0)
+    mg = torch.Generator().manual_seed(6)
+    masks = {k: (R.draw_masks(3, 12, 80, mg), ([], [])) for k in keys}
+    defaults = vars(add_enc_dec_teacher_filter_args(argparse.ArgumentParser()).parse_args([]))
+    args = argparse.Namespace(**dict(defaults, teacher_filter_decode_agreement=True, teacher_decode_agreement_temperature=0.6,
+                                     teacher_decode_agreement_min_similarity=0.65))
+    args.__dict__.update(dict(config={'model': {'subsampling_factor': 8}, 'audio_chunking': {'size': 2048, 'overlap': 0}, 'training': {}},
+                              optim_lr=1e-4, epochs=1, shuffle=False, training_mode='teacher_ce', spec_augment_fixed_masks=masks,
+                              dropout_emb=0.1, dropout_post_ff=0.1, dropout_attn=0.1, random_seed=3))
+    decisions, trace = [], []
+
+    def skip_fn(tokens, text, frames, agreement_text):
+        s, _ = should_skip_faulty_teacher_prediction(args=args, teacher_pred_tokens=tokens, teacher_pred_text=text, spec_frames=frames,
+                                                     agreement_text=agreement_text)
+        decisions.append(s)
+        return s
+
+    want, p_ref = enc_dec_dynamic_eval_ref(ref, spec, 256, tok, MADGRAD_REF, {'lr': 1e-4}, epochs=1, fixed_masks=masks, return_params=True,
+                                           skip_fn=skip_fn, dropout_emb=0.1, dropout_post_ff=0.1, dropout_attn=0.1, agreement_temperature=0.6,
+                                           random_seed=3, trace=trace)
+    assert any(a is not None and a != t for t, a in trace), "the sampled decode should differ from the greedy teacher somewhere"
+    before = hip.flat_params.clone()
+    got, p = enc_dec_dynamic_eval(args, hip, spec, 256, 0, tok, use_tqdm=False, return_params=True)
+    assert torch.equal(hip.flat_params, before) and got == want
+    assert any(decisions) and not all(decisions), f"seeded case: the first window is rejected (1 - CER 0.55 < 0.65), the others train: {decisions}"
+    for a, b in zip(p, p_ref):
+        assert (a - b).abs().max().item() < 5e-5
+    assert hip.language_model_decoder.training is False and all(l[0].fn.dropout_p == 0 for l in hip.language_model_decoder.layers)
+
+
 def test_enc_dec_harnesses(cuda, tmp_path, capsys):
     """enc_dec_dynamic_eval_test.py / enc_dec_inference_test.py mirrors: flags, stdout lines, -log line, pickle keys."""
     from dynamic_asr_eval_amd import enc_dec_dynamic_eval_test as A, enc_dec_inference_test as I, lib

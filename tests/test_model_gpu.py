@@ -178,7 +178,12 @@ def test_dynamic_eval_with_the_128_piece_tokenizer_reaches_the_wide_ctc_lattices
         f"pseudo-label lengths {tok_hip.lengths}: expected one window in [512, 1023] and one in [1024, 2047]"
     err = np.abs(out - out_ref).max()
     assert out.shape == out_ref.shape and err < 1e-3, f"adapted, stitched log-probs differ by {err} (bar: 1e-3 fp32)"
-    assert np.array_equal(out.argmax(-1), out_ref.argmax(-1)), "CTC argmax ids must be bit-exact"
+    # argmax ids bit-exact, except at frames whose top-2 margin IN THE ORACLE is below 5e-5 (under the fp32 summation-order noise of
+    # either side: this seeded 129-class model emits near-uniform posteriors, margins of 1e-5 occur among its 3072 frames)
+    bad = out.argmax(-1) != out_ref.argmax(-1)
+    top2 = np.sort(out_ref, -1)[:, -2:]
+    assert not (bad & ((top2[:, 1] - top2[:, 0]) >= 5e-5)).any(), "CTC argmax ids differ away from a near-tie"
+    assert int(bad.sum()) <= 3, f"{int(bad.sum())} near-tie frames differ"
 
 
 def test_dynamic_eval_short_recording_and_epochs0(cuda):

@@ -73,6 +73,22 @@ def test_oracle_stitch_reproduces_the_reference_statements(pins, tag):
         assert out.shape == want.shape == (case["out_rows"], C) and np.array_equal(out, want), (tag, ci)
 
 
+def test_fetch_utterances_reproduces_the_reference(pins, tmp_path):
+    """wav2vec2/tedlium/run.py:56-83: the utterance list `dynamic_eval_su` is fed (sample ranges, per-utterance text, joined text)."""
+    from dynamic_asr_eval_amd.datasets import fetch_utterances
+    _, meta = pins
+    ref = meta["fetch_utterances"]
+    stm = tmp_path / "talk.stm"
+    stm.write_text("\n".join(meta["stm"]["lines"]))
+    wave = torch.arange(ref["wave_samples"], dtype=torch.float32)[None] * 0.5
+    utts, all_text = fetch_utterances(str(stm), wave, ref["sample_rate"])
+    assert all_text == ref["all_text"] and len(utts) == len(ref["utterances"])
+    for u, r in zip(utts, ref["utterances"]):
+        assert (u["start"], u["end"], u["text"], u["start_frame"], u["end_frame"]) == (r["start"], r["end"], r["text"], r["start_frame"], r["end_frame"])
+        assert list(u["waveform"].shape) == r["shape"] and float(u["waveform"][0, 0]) == r["first"] and float(u["waveform"][0, -1]) == r["last"]
+        assert u["waveform"].data_ptr() == wave[:, r["start_frame"]:].data_ptr()          # a view of the resident talk, not a copy
+
+
 def test_stm_text_handling_reproduces_the_reference(pins):
     from dynamic_asr_eval_amd.datasets import proc_stm_lines
     _, meta = pins

@@ -183,6 +183,42 @@ def test_chunked_dynamic_eval_at_the_reference_window(cuda, base_pair):
     assert err < 1e-3 and not (bad & ((top2[:, 1] - top2[:, 0]) >= 5e-5)).any(), (err, int(bad.sum()))
 
 
+def test_dynamic_eval_su_at_the_base_960h_shape(cuda, base_pair):
+    """BASELINE config 3's named loop (`dynamic_eval_ctc_loss_su`, reference wav2vec2/lib.py:293-462) at the architecture the
+    reference loads (Wav2Vec2Config() defaults, 94.4 M parameters): 4 utterances of 2-6 s cut out of one talk by the reference's own
+    `fetch_utterances` rule (tedlium/run.py:56-83, pinned in tests/test_reference_pins.py), weights carried from utterance to
+    utterance, against oracle/wav2vec2_ref.py on the transformers CPU model."""
+    import argparse
+    from oracle.wav2vec2_ref import dynamic_eval_su_ref
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import wav2vec2_lib as W
+    from dynamic_asr_eval_amd.datasets import fetch_utterances_from_lines
+    ref, hip = base_pair
+    tok = W.CharTokenizer()
+    sr = 16000
+    lines = ["talk 1 spk 0.00 2.10 <o> a b c", "talk 1 spk 2.10 8.00 <o> d e", "talk 1 spk 8.00 9.50 <o> ignore_time_segment_in_scoring",
+             "talk 1 spk 9.50 13.25 <o> f", "talk 1 spk 13.25 17.40 <o> g h"]
+    wave = torch.randn(1, int(17.4 * sr), generator=torch.Generator().manual_seed(21)) * 0.1 + 0.02
+    utts, _ = fetch_utterances_from_lines(lines, wave, sr)
+    assert [u['waveform'].shape[1] for u in utts] == [33600, 94400, 60000, 66400]
+    utts_ref = [{'waveform': u['waveform'].clone()} for u in utts]
+    args = argparse.Namespace(epochs=1, shuffle=False)
+    before = hip.flat_params.clone()
+    dynamic_eval_su_ref(args, ref, utts_ref, tok, MADGRAD_REF, lr_args={'lr': 1e-6})
+    W.dynamic_eval_su(args, hip, utts, 0, 0, tok, None, use_tqdm=False, optim=W.MADGRAD, lr_args={'lr': 1e-6})
+    assert torch.equal(hip.flat_params, before), "weights must be restored (reference wav2vec2/lib.py:455-456)"
+    worst = 0.0
+    for k, (a, b) in enumerate(zip(utts, utts_ref)):
+        assert a['probs'].shape == b['probs'].shape and torch.isfinite(b['probs']).all()
+        err = (a['probs'].cpu() - b['probs']).abs().max().item()
+        worst = max(worst, err)
+        assert err < 1e-3, f"utterance {k}: log-probs differ by {err}"
+        bad = a['probs'].cpu().argmax(-1) != b['probs'].argmax(-1)
+        top2 = b['probs'].topk(2, -1).values
+        assert not (bad & ((top2[:, 0] - top2[:, 1]) >= 5e-5)).any(), f"utterance {k}: argmax differs away from a near-tie"
+    print("dynamic_eval_su at base-960h: worst |dlogp| over 4 weight-carrying utterances", worst)
+
+
 def test_run_wav2vec2_harness(cuda, tmp_path, capsys):
     """run_wav2vec2.py: both reference drivers' flow (tedlium/run.py -> dynamic_eval_su, earnings22/run.py -> dynamic_eval), the
     reference's flags, stdout lines and -log line; a local HF state_dict loads through -c and a foreign one is refused."""
