@@ -25,12 +25,20 @@ constexpr int D = 128, BQ = 128, BKEY = 32, TILE = BKEY * D;   // floats per K o
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ v, float* __restrict__ out, int64_t T,
                                                             int64_t row_stride, int64_t batch_stride, int64_t out_row_stride,
-                                                            int64_t out_batch_stride, float scale, float* __restrict__ lse) {
+                                                            int64_t out_batch_stride, float scale, float* __restrict__ lse,
+                                                            int nsplit, int64_t out_split_stride, int64_t lse_split_stride) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * TILE];   // 2 stages x (K tile, V tile) = 64 KB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int64_t b = blockIdx.z, head = blockIdx.y;
-    const int64_t q0 = (int64_t)blockIdx.x * BQ + wave * 32;
+    // key split (nsplit > 1): workgroup (query block, split) walks only its share of the key tiles and writes a NORMALISED partial
+    // output plus its log-sum-exp to the split's slab; attention_merge_kernel combines the slabs (the launch then has nsplit times
+    // the workgroups: 4 x 6 x 16 = 384 workgroups of the B = 4 final pass fill 0.75 of the 512 slots, 768 half-size ones balance)
+    const int split = nsplit > 1 ? (int)(blockIdx.x % nsplit) : 0;
+    const int64_t qblock = nsplit > 1 ? blockIdx.x / nsplit : blockIdx.x;
+    const int64_t q0 = qblock * BQ + wave * 32;
+    out += (int64_t)split * out_split_stride;
+    if (lse != nullptr) lse += (int64_t)split * lse_split_stride;
     const float* qb = q + b * batch_stride + head * D;
     const float* kb = k + b * batch_stride + head * D;
     const float* vb = v + b * batch_stride + head * D;
@@ -82,13 +90,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;     // running maximum / sum of this lane's query (both lane halves hold the same values)
 
-    const int64_t ntiles = (T + BKEY - 1) / BKEY;
-    set_src(0);
+    const int64_t ntiles_all = (T + BKEY - 1) / BKEY;
+    const int64_t per_split = (ntiles_all + nsplit - 1) / nsplit;
+    const int64_t kt0 = split * per_split;
+    const int64_t ntiles = kt0 + per_split < ntiles_all ? kt0 + per_split : ntiles_all;     // the host guarantees kt0 < ntiles
+    set_src(kt0 * BKEY);
     issue(smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
-    for (int64_t kt = 0; kt < ntiles; ++kt) {
+    for (int64_t kt = kt0; kt < ntiles; ++kt) {
         const float* ks = smem + cur * 2 * TILE;
         const float* vs = ks + TILE;
         if (kt + 1 < ntiles) {
@@ -160,6 +171,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (row < T)
             *reinterpret_cast<float4*>(ob + row * out_row_stride + 4 * i) = make_float4(o[0][e] * w, o[1][e] * w, o[2][e] * w, o[3][e] * w);
     }
+}
+
+// out[b, row, head, :] = sum_s w_s * part_s[b, row, head, :],  w_s = exp(lse_s - lse),  lse = log sum_s exp(lse_s)  (fixed order in s).
+// One thread per 16 B of output; part / out share the row and batch strides, the slabs are `split_stride` floats apart.
+__global__ __launch_bounds__(256) void attention_merge_kernel(const float* __restrict__ part, const float* __restrict__ part_lse,
+                                                              float* __restrict__ out, float* __restrict__ lse, int64_t B, int64_t T, int64_t H,
+                                                              int nsplit, int64_t part_row_stride, int64_t part_batch_stride,
+                                                              int64_t part_split_stride, int64_t lse_split_stride, int64_t out_row_stride,
+                                                              int64_t out_batch_stride) {
+    const int64_t total = B * T * H * (D / 4);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % (D / 4));
+        const int64_t r = idx / (D / 4);
+        const int64_t head = r % H, row = (r / H) % T, b = r / (H * T);
+        const float* lp = part_lse + (b * H + head) * T + row;
+        float m = -INFINITY;
+        for (int s = 0; s < nsplit; ++s) m = fmaxf(m, lp[(int64_t)s * lse_split_stride]);
+        float den = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < nsplit; ++s) {
+            const float w = __expf(lp[(int64_t)s * lse_split_stride] - m);
+            const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)s * part_split_stride + b * part_batch_stride + row * part_row_stride + head * D + 4 * c4);
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+            den += w;
+        }
+        const float inv = 1.f / den;
+        *reinterpret_cast<float4*>(out + b * out_batch_stride + row * out_row_stride + head * D + 4 * c4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        if (lse != nullptr && c4 == 0) lse[(b * H + head) * T + row] = m + __logf(den);
+    }
+}
+
+// Key splits of a launch: none when the (batch, head, query block) workgroups already fill the 512 slots (2 per CU); otherwise the
+// smallest count that brings the launch to ~480 workgroups, with at least 8 key tiles (256 keys) per split and at most 8 splits.
+int pick_splits(int64_t B, int64_t T, int64_t H) {
+    const int64_t wgs = B * H * dyn::cdiv(T, BQ);
+    const int64_t ntiles = dyn::cdiv(T, BKEY);
+    if (wgs >= 448 || ntiles < 16) return 1;
+    int64_t s = dyn::cdiv(480, wgs);
+    if (s > ntiles / 8) s = ntiles / 8;
+    if (s > 8) s = 8;
+    return s < 1 ? 1 : (int)s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -346,34 +398,75 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
 
 // q / k / v: [B, T, .] views with row stride `row_stride` and batch stride `batch_stride` (floats), head h at +h * 128 (so the
 // packed [B, T, 3 * H * 128] QKV activation is passed as three base pointers); out [B, T, H * 128]-like with its own strides.
+namespace {
+int64_t split_ws_bytes(int64_t B, int64_t T, int64_t H, int nsplit) {
+    return nsplit > 1 ? (int64_t)nsplit * (B * T * H * D + B * H * T) * (int64_t)sizeof(float) : 0;
+}
+
+int launch_fwd(const char* what, const float* q, const float* k, const float* v, float* out, float* lse, int64_t B, int64_t T, int64_t H,
+               int64_t head_dim, int64_t row_stride, int64_t batch_stride, int64_t out_row_stride, int64_t out_batch_stride, float scale,
+               int nsplit, void* workspace, int64_t workspace_bytes, void* stream) {
+    DYN_REQUIRE(q && k && v && out && B >= 0 && T >= 0 && H > 0, DYN_E_ARG, "%s: bad arguments", what);
+    DYN_REQUIRE(head_dim == D, DYN_E_UNSUPPORTED, "%s: head_dim %lld (the fused kernel is built for 128)", what, (long long)head_dim);
+    DYN_REQUIRE(row_stride % 4 == 0 && batch_stride % 4 == 0 && out_row_stride % 4 == 0 && out_batch_stride % 4 == 0 &&
+                    ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0, DYN_E_ARG,
+                "%s: q / k / v / out must be 16-byte aligned with strides that are multiples of 4 floats", what);
+    if (B == 0 || T == 0) return DYN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (nsplit == 0) nsplit = workspace ? pick_splits(B, T, H) : 1;
+    const int64_t ntiles = dyn::cdiv(T, BKEY);
+    DYN_REQUIRE(nsplit >= 1 && nsplit <= 8 && (nsplit == 1 || (int64_t)(nsplit - 1) * dyn::cdiv(ntiles, nsplit) < ntiles), DYN_E_ARG,
+                "%s: %d key splits do not fit %lld key tiles", what, nsplit, (long long)ntiles);
+    if (nsplit == 1) {
+        dim3 grid((unsigned)dyn::cdiv(T, BQ), (unsigned)H, (unsigned)B);
+        hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 0, st, q, k, v, out, T, row_stride, batch_stride, out_row_stride,
+                           out_batch_stride, scale, lse, 1, (int64_t)0, (int64_t)0);
+        return dyn::check_launch(what);
+    }
+    DYN_REQUIRE(workspace && workspace_bytes >= split_ws_bytes(B, T, H, nsplit) && (((uintptr_t)workspace) & 15) == 0, DYN_E_WORKSPACE,
+                "%s: %d key splits need %lld workspace bytes (16-byte aligned), got %lld", what, nsplit,
+                (long long)split_ws_bytes(B, T, H, nsplit), (long long)workspace_bytes);
+    float* part = (float*)workspace;                       // [nsplit][B][T][H * D]
+    const int64_t part_split = B * T * H * D;
+    float* part_lse = part + (int64_t)nsplit * part_split;   // [nsplit][B][H][T]
+    const int64_t lse_split = B * H * T;
+    dim3 grid((unsigned)(dyn::cdiv(T, BQ) * nsplit), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 0, st, q, k, v, part, T, row_stride, batch_stride, H * D, T * H * D, scale,
+                       part_lse, nsplit, part_split, lse_split);
+    int64_t g = dyn::cdiv(B * T * H * (D / 4), 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)g), dim3(256), 0, st, part, part_lse, out, lse, B, T, H, nsplit, H * D, T * H * D,
+                       part_split, lse_split, out_row_stride, out_batch_stride);
+    return dyn::check_launch(what);
+}
+}  // namespace
+
 extern "C" int dyn_attention_fwd(const float* q, const float* k, const float* v, float* out, int64_t B, int64_t T, int64_t H,
                                  int64_t head_dim, int64_t row_stride, int64_t batch_stride, int64_t out_row_stride,
                                  int64_t out_batch_stride, float scale, void* stream) {
-    DYN_REQUIRE(q && k && v && out && B >= 0 && T >= 0 && H > 0, DYN_E_ARG, "dyn_attention_fwd: bad arguments");
-    DYN_REQUIRE(head_dim == D, DYN_E_UNSUPPORTED, "dyn_attention_fwd: head_dim %lld (the fused kernel is built for 128)", (long long)head_dim);
-    DYN_REQUIRE(row_stride % 4 == 0 && batch_stride % 4 == 0 && out_row_stride % 4 == 0 && out_batch_stride % 4 == 0 &&
-                    ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0, DYN_E_ARG,
-                "dyn_attention_fwd: q / k / v / out must be 16-byte aligned with strides that are multiples of 4 floats");
-    if (B == 0 || T == 0) return DYN_OK;
-    dim3 grid((unsigned)dyn::cdiv(T, BQ), (unsigned)H, (unsigned)B);
-    hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, row_stride, batch_stride,
-                       out_row_stride, out_batch_stride, scale, (float*)nullptr);
-    return dyn::check_launch("dyn_attention_fwd");
+    return launch_fwd("dyn_attention_fwd", q, k, v, out, nullptr, B, T, H, head_dim, row_stride, batch_stride, out_row_stride, out_batch_stride,
+                      scale, 1, nullptr, 0, stream);
 }
 
 extern "C" int dyn_attention_fwd_lse(const float* q, const float* k, const float* v, float* out, float* lse, int64_t B, int64_t T,
                                      int64_t H, int64_t head_dim, int64_t row_stride, int64_t batch_stride, int64_t out_row_stride,
                                      int64_t out_batch_stride, float scale, void* stream) {
-    DYN_REQUIRE(q && k && v && out && lse && B >= 0 && T >= 0 && H > 0, DYN_E_ARG, "dyn_attention_fwd_lse: bad arguments");
-    DYN_REQUIRE(head_dim == D, DYN_E_UNSUPPORTED, "dyn_attention_fwd_lse: head_dim %lld (the fused kernel is built for 128)", (long long)head_dim);
-    DYN_REQUIRE(row_stride % 4 == 0 && batch_stride % 4 == 0 && out_row_stride % 4 == 0 && out_batch_stride % 4 == 0 &&
-                    ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0, DYN_E_ARG,
-                "dyn_attention_fwd_lse: q / k / v / out must be 16-byte aligned with strides that are multiples of 4 floats");
-    if (B == 0 || T == 0) return DYN_OK;
-    dim3 grid((unsigned)dyn::cdiv(T, BQ), (unsigned)H, (unsigned)B);
-    hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, T, row_stride, batch_stride,
-                       out_row_stride, out_batch_stride, scale, lse);
-    return dyn::check_launch("dyn_attention_fwd_lse");
+    DYN_REQUIRE(lse, DYN_E_ARG, "dyn_attention_fwd_lse: lse is NULL");
+    return launch_fwd("dyn_attention_fwd_lse", q, k, v, out, lse, B, T, H, head_dim, row_stride, batch_stride, out_row_stride, out_batch_stride,
+                      scale, 1, nullptr, 0, stream);
+}
+
+extern "C" int64_t dyn_attention_fwd_split_workspace_bytes(int64_t B, int64_t T, int64_t H, int32_t nsplit) {
+    if (B <= 0 || T <= 0 || H <= 0) return 0;
+    return split_ws_bytes(B, T, H, nsplit == 0 ? pick_splits(B, T, H) : nsplit);
+}
+
+extern "C" int dyn_attention_fwd_split(const float* q, const float* k, const float* v, float* out, float* lse, int64_t B, int64_t T,
+                                       int64_t H, int64_t head_dim, int64_t row_stride, int64_t batch_stride, int64_t out_row_stride,
+                                       int64_t out_batch_stride, float scale, int32_t nsplit, void* workspace, int64_t workspace_bytes,
+                                       void* stream) {
+    return launch_fwd("dyn_attention_fwd_split", q, k, v, out, lse, B, T, H, head_dim, row_stride, batch_stride, out_row_stride,
+                      out_batch_stride, scale, nsplit, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dyn_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout, const float* lse,

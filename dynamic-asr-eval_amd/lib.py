@@ -458,6 +458,33 @@ def dynamic_eval_ctc_loss(args, model, spec, seq_len, overlap, tokenizer, use_tq
         return stop.value
 
 
+def _new_chain_stream(device, k):
+    """Stream of recording chain k.  DYN_CHAIN_CU_MASK=<n>[:stride] (experiment switch, off by default) gives chain k a stream whose
+    kernels may not use a group of n of the 256 CUs — CUs k*n .. k*n+n-1, or with `:stride` every (256/n)-th CU starting at k — so the
+    short kernels of the OTHER chains can start there while a matrix kernel of chain k holds the rest of the chip
+    (dyn_stream_create_cu_mask = hipExtStreamCreateWithCUMask).  Measured: DESIGN.md §5."""
+    import ctypes
+    import os
+    spec = os.environ.get("DYN_CHAIN_CU_MASK", "")
+    if not spec or spec == "0":
+        return torch.cuda.Stream(device=device)
+    from ._lib import check, load
+    n = int(spec.split(":")[0])
+    strided = spec.endswith(":stride")
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    if not 0 < n < n_cu:
+        raise ops.DynError(f"DYN_CHAIN_CU_MASK={spec!r}: hole size must be in 1..{n_cu - 1}")
+    hole = {(k + j * (n_cu // n)) % n_cu for j in range(n)} if strided else {(k * n + j) % n_cu for j in range(n)}
+    words = (ctypes.c_uint32 * ((n_cu + 31) // 32))()
+    for cu in range(n_cu):
+        if cu not in hole:
+            words[cu // 32] |= 1 << (cu % 32)
+    out = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        check(load().dyn_stream_create_cu_mask(words, len(words), ctypes.byref(out)), "dyn_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(out.value, device=device)
+
+
 _CHAIN_STREAMS = {}
 HOST_WAIT = [0.0]   # seconds the host spent blocked on the per-window pseudo-label ids (diagnostic)
 
@@ -470,7 +497,7 @@ def dynamic_eval_many(args, models, specs, seq_len, overlap, tokenizer, **kw):
     device = models[0].device
     key = torch.device(device).index
     while len(_CHAIN_STREAMS.setdefault(key, [])) < len(models):    # streams are kept: the caching allocator's per-stream
-        _CHAIN_STREAMS[key].append(torch.cuda.Stream(device=device))  # pools stay warm across calls (no hipMalloc in the loop)
+        _CHAIN_STREAMS[key].append(_new_chain_stream(device, len(_CHAIN_STREAMS[key])))  # pools stay warm across calls (no hipMalloc in the loop)
     streams = _CHAIN_STREAMS[key][:len(models)]
     main = torch.cuda.current_stream(device)
     for st in streams:

@@ -420,23 +420,30 @@ def specaug_timemask(x, t0, width, value=0.0):
     return x
 
 
-def attention_fwd(qkv, B, T, H, D, scale, out=None, want_lse=False):
+ATTN_NSPLIT_DEFAULT = int(_os.environ.get("DYN_ATTN_NSPLIT", "0"))
+
+
+def attention_fwd(qkv, B, T, H, D, scale, out=None, want_lse=False, nsplit=0):
     """Fused attention on the packed [B, T, 3 * H * D] QKV activation (q | k | v, head h at +h * D) -> [B, T, H * D];
-    with `want_lse` (grad mode) returns (out, lse [B, H, T]) for attention_bwd."""
+    with `want_lse` (grad mode) returns (out, lse [B, H, T]) for attention_bwd.  `nsplit`: key splits per query block (0 = chosen
+    by the library from the launch size, 1 = none): launches that do not fill the chip get nsplit x the workgroups, the partial
+    outputs go through the caller's workspace and are merged in split order."""
     _cc(qkv, "attention.qkv")
     HD = H * D
     out = torch.empty(B, T, HD, device=qkv.device, dtype=F32) if out is None else out
     if GEMM_PROFILE is not None:
         GEMM_PROFILE["attn_flops"] = GEMM_PROFILE.get("attn_flops", 0.0) + 4.0 * B * H * T * T * D   # matrix-core work outside dyn_gemm_f32
     base = qkv.data_ptr()
-    if want_lse:
-        lse = torch.empty(B, H, T, device=qkv.device, dtype=F32)
-        check(_L().dyn_attention_fwd_lse(base, base + 4 * HD, base + 8 * HD, out.data_ptr(), lse.data_ptr(), B, T, H, D, 3 * HD, T * 3 * HD,
-                                         HD, T * HD, scale, _stream()), "dyn_attention_fwd_lse")
-        return out, lse
-    check(_L().dyn_attention_fwd(base, base + 4 * HD, base + 8 * HD, out.data_ptr(), B, T, H, D, 3 * HD, T * 3 * HD, HD, T * HD, scale,
-                                 _stream()), "dyn_attention_fwd")
-    return out
+    lse = torch.empty(B, H, T, device=qkv.device, dtype=F32) if want_lse else None
+    if nsplit == 0 and ATTN_NSPLIT_DEFAULT:
+        nsplit = ATTN_NSPLIT_DEFAULT     # A/B switch only (DYN_ATTN_NSPLIT=1: never split)
+    ws = workspace(qkv.device)
+    need = _L().dyn_attention_fwd_split_workspace_bytes(B, T, H, nsplit)
+    if need > ws.numel():
+        nsplit = 1                      # scratch too small for the slabs (very long windows): the unsplit launch needs none
+    check(_L().dyn_attention_fwd_split(base, base + 4 * HD, base + 8 * HD, out.data_ptr(), 0 if lse is None else lse.data_ptr(), B, T, H, D,
+                                       3 * HD, T * 3 * HD, HD, T * HD, scale, nsplit, ws.data_ptr(), ws.numel(), _stream()), "dyn_attention_fwd_split")
+    return (out, lse) if want_lse else out
 
 
 def attention_bwd(qkv, out, dout, lse, B, T, H, D, scale, dqkv=None):

@@ -236,6 +236,12 @@ int dyn_cutout(float* x, int64_t F, int64_t T, const int32_t* rects, int64_t n_r
  * lib.dynamic_eval_many out of phase.  No reference counterpart (the reference runs one recording at a time,
  * run_dynamic_eval_full.py:84-100); scheduling aid only, computes nothing. */
 int dyn_sleep_us(int64_t microseconds, void* stream);
+/* A HIP stream restricted to the compute units set in `mask` (bit i of word i / 32 = CU i, hipExtStreamCreateWithCUMask), and its
+ * destruction.  lib.dynamic_eval_many can run its recording chains on such streams (DYN_CHAIN_CU_MASK=<hole size>): chain k's kernels
+ * then leave a different group of CUs free, on which the short kernels of the other chains can start while a matrix kernel of chain k
+ * owns the rest of the chip.  No reference counterpart; scheduling aid only (A/B result in DESIGN.md §5). */
+int dyn_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, void** stream_out);
+int dyn_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused self-attention forward for no-grad passes (reference lcasr/lib.py:603: the final pass runs model(audio_signal) under
@@ -251,6 +257,14 @@ int dyn_attention_fwd(const float* q, const float* k, const float* v, float* out
 int dyn_attention_fwd_lse(const float* q, const float* k, const float* v, float* out, float* lse, int64_t B, int64_t T, int64_t H,
                           int64_t head_dim, int64_t row_stride, int64_t batch_stride, int64_t out_row_stride,
                           int64_t out_batch_stride, float scale, void* stream);
+/* The same forward with the KEYS split over `nsplit` workgroups per query block (0 = chosen from the launch size, 1 = no split,
+ * at most 8): each split writes a normalised partial output and its log-sum-exp to `workspace`, a second kernel merges them in
+ * split order (deterministic).  For launches whose (batch, head, query-block) workgroups do not fill the chip: the B = 4 final-pass
+ * launch at T' = 2048 (384 workgroups on 512 slots) and every B = 1 inference.  `lse` may be NULL. */
+int64_t dyn_attention_fwd_split_workspace_bytes(int64_t B, int64_t T, int64_t H, int32_t nsplit);
+int dyn_attention_fwd_split(const float* q, const float* k, const float* v, float* out, float* lse, int64_t B, int64_t T, int64_t H,
+                            int64_t head_dim, int64_t row_stride, int64_t batch_stride, int64_t out_row_stride, int64_t out_batch_stride,
+                            float scale, int32_t nsplit, void* workspace, int64_t workspace_bytes, void* stream);
 /* Backward of the fused attention (`loss.backward()`, reference lcasr/lib.py:579, through softmax(q k^T) v): dq / dk / dv from
  * (q, k, v, out, dout, lse), recomputing P tile by tile from LDS-staged tiles — no [T, T] matrix is read or written.
  * Deterministic (no float atomics): query-owner workgroups produce dq and delta [B, H, T] (scratch: rowsum(dout * out)), then

@@ -4,8 +4,8 @@
 out=$1; shift
 mkdir -p "$out"
 ROUNDS=${ROUNDS:-2}
-ARGS=${ARGS:---steps 3 --warmup 0 --prewarm_s 20 --no_cpu_baseline --side_steps 0}
-python bench.py --steps 3 --warmup 0 --prewarm_s 30 --no_cpu_baseline --side_steps 0 > "$out/warm.json" 2>/dev/null
+ARGS=${ARGS:---steps 3 --warmup 0 --prewarm_s 20 --no_cpu_baseline --side_steps 0 --side_workloads 0}
+python bench.py --steps 3 --warmup 0 --prewarm_s 30 --no_cpu_baseline --side_steps 0 --side_workloads 0 > "$out/warm.json" 2>/dev/null
 for r in $(seq 1 $ROUNDS); do
   for cfg in "$@"; do
     name=${cfg%%:*}; envs=${cfg#*:}

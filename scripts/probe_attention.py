@@ -64,3 +64,19 @@ for T in [int(a) for a in sys.argv[1:]] or [2048, 8192]:
           f"backward B={B_b}: unfused {t_ub*1e3:.0f} us ({fl_b4/t_ub/1e9:.0f} TF/s on 4 products) | fused {t_fb*1e3:.0f} us "
           f"({fl_b7/t_fb/1e9:.0f} TF/s on 7 products, {fl_b4/t_fb/1e9:.0f} useful)   scores kept: unfused {B_f*H*T*T*4/1e9:.2f} GB, fused {B_f*H*T*4/1e6:.2f} MB", flush=True)
     del S, S1
+
+# no-grad forward with key splits (dyn_attention_fwd_split): the final pass (B = 4), the adapt step (B = 2), plain inference (B = 1)
+for T in [int(a) for a in sys.argv[1:]] or [2048]:
+    scale = 1.0 / math.sqrt(D)
+    for B in (4, 2, 1):
+        qkv = torch.randn(B, T, 3 * HD, device=dev)
+        fl = 4.0 * B * H * T * T * D
+        line = f"T'={T} no-grad forward B={B} ({B * H * ((T + 127) // 128)} query-block workgroups):"
+        for ns in (1, 0, 2, 3, 4, 6, 8):
+            try:
+                t = timeit(lambda: ops.attention_fwd(qkv, B, T, H, D, scale, nsplit=ns), n=20)
+            except Exception as e:
+                line += f"  nsplit={ns}: n/a"
+                continue
+            line += f"  nsplit={'auto' if ns == 0 else ns}: {t*1e3:.0f} us ({fl/t/1e9:.0f} TF/s)"
+        print(line, flush=True)

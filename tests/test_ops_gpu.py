@@ -228,8 +228,9 @@ def test_ctc_loss_and_grad(cuda, T, C, S, reduction):
                                    reduction=reduction, grad_scale=scale)
     rel = abs(loss.item() - loss_ref.item()) / max(1.0, abs(loss_ref.item()))
     assert rel < 2e-6 * max(1, T // 64), (loss.item(), loss_ref.item())   # fp32 lattice, T serial log-sum-exps
-    # |grad| <= scale per element; the fp32 lattice's log-domain error grows with the T serial log-sum-exps
-    _close(grad, lpr.grad, scale * max(1.3e-3, 2e-6 * T), "ctc grad")
+    # |grad| <= scale per element; the fp32 lattice's log-domain error grows with the T serial log-sum-exps and with |alpha| ~ T * |lp|
+    # (ulp(20000) = 2e-3 at T = 4200, C = 129: torch's own fp32 lattice is as far from float64 as this one, scripts/drift_check.py)
+    _close(grad, lpr.grad, scale * max(1.3e-3, 4e-6 * T), "ctc grad")
 
 
 def test_optimizers_match_torch(cuda):
@@ -341,6 +342,35 @@ def test_fused_attention_forward(cuda, B, T, H):
     ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(B, T, H * D)
     err = (out.cpu().double() - ref).abs().max().item()
     assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("B,T,H,nsplit", [(1, 2048, 6, 0), (4, 2048, 6, 0), (1, 1000, 2, 3), (2, 513, 1, 2), (1, 4096, 1, 8), (1, 640, 3, 2)])
+def test_fused_attention_forward_with_key_splits(cuda, B, T, H, nsplit):
+    """dyn_attention_fwd_split: the keys of a query block split over several workgroups (normalised partial outputs + log-sum-exp
+    per split, merged in split order) — automatic choice (0) and forced counts, ragged T, output AND lse vs float64; identical
+    results on a second run; nsplit = 1 is bit-identical to the unsplit entry point."""
+    from dynamic_asr_eval_amd import ops
+    D = 128
+    g = torch.Generator().manual_seed(B * 31 + T + H + nsplit)
+    qkv = (torch.randn(B, T, 3 * H * D, generator=g) * 1.5).to(cuda)
+    scale = 1.0 / D ** 0.5
+    out, lse = ops.attention_fwd(qkv, B, T, H, D, scale, want_lse=True, nsplit=nsplit)
+    x = qkv.cpu().double().view(B, T, 3, H, D)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    sc = q @ k.transpose(-1, -2) * scale
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B, T, H * D)
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+    assert (lse.cpu().double() - torch.logsumexp(sc, -1)).abs().max().item() < 2e-5
+    out2 = ops.attention_fwd(qkv, B, T, H, D, scale, nsplit=nsplit)
+    assert torch.equal(out, out2)
+    one, lse1 = ops.attention_fwd(qkv, B, T, H, D, scale, want_lse=True, nsplit=1)
+    from dynamic_asr_eval_amd._lib import check, load
+    base, HD = qkv.data_ptr(), H * D
+    plain = torch.empty_like(one)
+    check(load().dyn_attention_fwd(base, base + 4 * HD, base + 8 * HD, plain.data_ptr(), B, T, H, D, 3 * HD, T * 3 * HD, HD, T * HD, scale,
+                                   torch.cuda.current_stream().cuda_stream), "dyn_attention_fwd")
+    assert torch.equal(one, plain)
+    assert (one - out).abs().max().item() < 2e-5
 
 
 @pytest.mark.parametrize("B,T,H", [(1, 100, 6), (2, 257, 6), (1, 2048, 6), (2, 33, 1), (1, 128, 2)])
