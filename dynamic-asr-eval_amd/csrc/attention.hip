@@ -202,13 +202,15 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const float* __res
     }
 }
 
-// Key splits of a launch: none when the (batch, head, query block) workgroups already fill the 512 slots (2 per CU); otherwise the
-// smallest count that brings the launch to ~480 workgroups, with at least 8 key tiles (256 keys) per split and at most 8 splits.
+// Key splits of a launch.  Measured at T' = 2048, H = 6 (profiles/r03_probe_attention.log): the kernel is fastest when the launch has
+// 768 workgroups = exactly three per CU (two resident, the third follows): B = 4 (384 query-block workgroups) 574 us unsplit, 443 us
+// with 2 splits, 495 with 3 (2.25 per CU: unbalanced), 454 with 4; B = 2 (192): 304 -> 234 us with 4; B = 1 (96): 299 -> 130 us with 8.
+// So: the split count that brings the launch closest to 768 workgroups, at least 8 key tiles (256 keys) per split, at most 8 splits.
 int pick_splits(int64_t B, int64_t T, int64_t H) {
     const int64_t wgs = B * H * dyn::cdiv(T, BQ);
     const int64_t ntiles = dyn::cdiv(T, BKEY);
-    if (wgs >= 448 || ntiles < 16) return 1;
-    int64_t s = dyn::cdiv(480, wgs);
+    if (wgs >= 640 || ntiles < 16) return 1;
+    int64_t s = (768 + wgs / 2) / wgs;
     if (s > ntiles / 8) s = ntiles / 8;
     if (s > 8) s = 8;
     return s < 1 ? 1 : (int)s;

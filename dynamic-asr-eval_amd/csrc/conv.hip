@@ -436,6 +436,203 @@ __global__ __launch_bounds__(256) void conv2d_s2_wgrad_v4_kernel(const float* __
     }
 }
 
+// ---- the first two subsampling stages FUSED: u2 = dw3x3_s2(silu(conv3x3_s2(x))) without the [B, T/2, F/2, C] intermediate ----
+// z1 = conv2d_first(x) is the largest activation of the model (671 MB at B = 2, T = 16384, C = 256) and is a pure function of the
+// one-channel input x (5 MB): writing it, reading it back for the depthwise conv and reading it twice more in the backward (plus the
+// 335 MB of its gradient, written and read once) is 2.7 GB of HBM traffic per adapt step for ~10 GFLOP.  The fused kernels
+// RECOMPUTE z1 from x on the fly (9 FMAs per element, x arrives through the scalar cache: the row index is wave-uniform) — forward
+// and backward — so neither z1 nor dz1 ever exists in HBM.  Same accumulation orders as the unfused kernels above (bias first, taps
+// dt-major): the forward output is bit-identical to conv2d_first_fwd_v4 + dwconv2d_s2_fwd_v4.
+//   forward : one wave per output row (b, t2), lane = 4 channels, sliding 3-column window of silu(z1) along f
+//   backward: one wave per tile of z1 rows; per z1 element: z1 again, dz1 = silu'(z1) * sum w2 * du2 (never stored), and straight
+//             into the four weight / bias gradient accumulators (conv1: dz1 * x taps; dw2: du2 * silu(z1)); partial rows per
+//             workgroup, summed in a fixed order by the 2-D reducers (deterministic, no atomics)
+__device__ __forceinline__ void fma4s(float4& a, const float4& w, float v) {
+    a.x += w.x * v; a.y += w.y * v; a.z += w.z * v; a.w += w.w * v;
+}
+
+__global__ __launch_bounds__(256) void sub12_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                         const float* __restrict__ b1, const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, float* __restrict__ u2, int64_t T, int F,
+                                                         int64_t T1, int F1, int64_t T2, int F2, int C, int64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: everything derived from `row` stays scalar
+    const int64_t row = (int64_t)blockIdx.x * 4 + wv;                       // (b, t2) flattened
+    if (row >= rows) return;
+    const int64_t b = row / T2, t2 = row % T2;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    // x rows 4 t2 - 3 .. 4 t2 + 3 feed the three z1 rows 2 t2 - 1 .. 2 t2 + 1
+    const float* xr[7];
+    bool xok[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const int64_t tx = 4 * t2 - 3 + r;
+        xok[r] = tx >= 0 && tx < T;
+        xr[r] = x + (b * T + (xok[r] ? tx : 0)) * F;
+    }
+    bool rok[3];
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+        const int64_t t1 = 2 * t2 + dt - 1;
+        rok[dt] = t1 >= 0 && t1 < T1;
+    }
+    for (int c0 = lane * 4; c0 < C; c0 += 256) {
+        float4 wa[9], wb[9];
+        load_w4(w1, c0, wa);
+        load_w4(w2, c0, wb);
+        const float4 b1v = *reinterpret_cast<const float4*>(b1 + c0);
+        const float4 b2v = *reinterpret_cast<const float4*>(b2 + c0);
+        float4 prev[3] = {zero, zero, zero};                  // silu(z1) at column 2 f2 - 1 (f1 = -1 for f2 = 0: padding)
+        float xprev[7];                                        // x column 4 f2 - 1
+#pragma unroll
+        for (int r = 0; r < 7; ++r) xprev[r] = 0.f;
+        float* ur = u2 + (row * F2) * C + c0;
+        for (int f2 = 0; f2 < F2; ++f2) {
+            float xv[7][5];                                    // x columns 4 f2 - 1 .. 4 f2 + 3
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                xv[r][0] = xprev[r];
+#pragma unroll
+                for (int k = 1; k < 5; ++k) {
+                    const int col = 4 * f2 - 1 + k;
+                    xv[r][k] = (xok[r] && col < F) ? xr[r][col] : 0.f;
+                }
+                xprev[r] = xv[r][4];
+            }
+            float4 s[3][2];
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float4 z = b1v;
+#pragma unroll
+                    for (int dtx = 0; dtx < 3; ++dtx)
+#pragma unroll
+                        for (int dfx = 0; dfx < 3; ++dfx) fma4s(z, wa[dtx * 3 + dfx], xv[2 * dt + dtx][2 * j + dfx]);
+                    s[dt][j] = (rok[dt] && 2 * f2 + j < F1) ? silu4(z) : zero;
+                }
+            float4 acc = b2v;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                fma4(acc, wb[dt * 3 + 0], prev[dt]);
+                fma4(acc, wb[dt * 3 + 1], s[dt][0]);
+                fma4(acc, wb[dt * 3 + 2], s[dt][1]);
+                prev[dt] = s[dt][1];
+            }
+            *reinterpret_cast<float4*>(ur + (int64_t)f2 * C) = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sub12_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du2,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, float* __restrict__ pw1, float* __restrict__ pb1,
+                                                         float* __restrict__ pw2, float* __restrict__ pb2, int64_t T, int F, int64_t T1,
+                                                         int F1, int64_t T2, int F2, int C, int64_t per, int64_t chunks, int64_t tiles) {
+    __shared__ float4 red[3][64][10];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;     // (b, chunk of z1 rows) flattened
+    const bool live = tile < tiles;
+    const int64_t b = live ? tile / chunks : 0, r0 = live ? (tile % chunks) * per : 0;
+    const int64_t r1 = live ? ((r0 + per < T1) ? r0 + per : T1) : 0;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int cb = 0; cb < C; cb += 256) {
+        const int c0 = cb + lane * 4;
+        const bool cok = c0 < C;
+        float4 wa[9], wb[9], a1[9], a2[9], ab1 = zero, ab2 = zero, b1v = zero;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { a1[j] = zero; a2[j] = zero; wa[j] = zero; wb[j] = zero; }
+        if (cok) {
+            load_w4(w1, c0, wa);
+            load_w4(w2, c0, wb);
+            b1v = *reinterpret_cast<const float4*>(b1 + c0);
+        }
+        for (int64_t t1 = r0; t1 < r1 && cok; ++t1) {
+            const float* xr[3];
+            bool xok[3];
+#pragma unroll
+            for (int dtx = 0; dtx < 3; ++dtx) {
+                const int64_t tx = 2 * t1 + dtx - 1;
+                xok[dtx] = tx >= 0 && tx < T;
+                xr[dtx] = x + (b * T + (xok[dtx] ? tx : 0)) * F;
+            }
+            const float* gr[3];                       // du2 rows that read z1 row t1 through tap row dt:  2 t2 + dt - 1 = t1
+            bool gok[3];
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                const int64_t tt = t1 + 1 - dt;
+                gok[dt] = tt >= 0 && !(tt & 1) && (tt >> 1) < T2;
+                gr[dt] = du2 + ((b * T2 + (gok[dt] ? (tt >> 1) : 0)) * F2) * C + c0;
+            }
+            for (int f1 = 0; f1 < F1; ++f1) {
+                float xv[3][3];
+#pragma unroll
+                for (int dtx = 0; dtx < 3; ++dtx)
+#pragma unroll
+                    for (int dfx = 0; dfx < 3; ++dfx) {
+                        const int col = 2 * f1 + dfx - 1;
+                        xv[dtx][dfx] = (xok[dtx] && col >= 0 && col < F) ? xr[dtx][col] : 0.f;
+                    }
+                float4 z = b1v;
+#pragma unroll
+                for (int dtx = 0; dtx < 3; ++dtx)
+#pragma unroll
+                    for (int dfx = 0; dfx < 3; ++dfx) fma4s(z, wa[dtx * 3 + dfx], xv[dtx][dfx]);
+                const float4 sz = silu4(z), sg = silu_grad4(z);
+                float4 g = zero;
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
+                    if (!gok[dt]) continue;
+#pragma unroll
+                    for (int df = 0; df < 3; ++df) {
+                        const int ff = f1 + 1 - df;
+                        if (ff < 0 || (ff & 1) || (ff >> 1) >= F2) continue;
+                        const float4 d = *reinterpret_cast<const float4*>(gr[dt] + (int64_t)(ff >> 1) * C);
+                        fma4(g, wb[dt * 3 + df], d);
+                        fma4(a2[dt * 3 + df], d, sz);
+                        if (dt == 1 && df == 1) { ab2.x += d.x; ab2.y += d.y; ab2.z += d.z; ab2.w += d.w; }   // every du2 element once
+                    }
+                }
+                const float4 dz = make_float4(g.x * sg.x, g.y * sg.y, g.z * sg.z, g.w * sg.w);
+                ab1.x += dz.x; ab1.y += dz.y; ab1.z += dz.z; ab1.w += dz.w;
+#pragma unroll
+                for (int dtx = 0; dtx < 3; ++dtx)
+#pragma unroll
+                    for (int dfx = 0; dfx < 3; ++dfx) fma4s(a1[dtx * 3 + dfx], dz, xv[dtx][dfx]);
+            }
+        }
+        // the four waves of the workgroup are summed in wave order through LDS (conv1 accumulators, then the depthwise ones)
+        const int64_t prow = blockIdx.x;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            float4* acc = pass == 0 ? a1 : a2;
+            float4& accb = pass == 0 ? ab1 : ab2;
+            __syncthreads();
+            if (wv > 0) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) red[wv - 1][lane][j] = acc[j];
+                red[wv - 1][lane][9] = accb;
+            }
+            __syncthreads();
+            if (wv == 0 && cok) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) { const float4 v = red[k][lane][j]; acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w; }
+                    const float4 v = red[k][lane][9];
+                    accb.x += v.x; accb.y += v.y; accb.z += v.z; accb.w += v.w;
+                }
+                float* pw = pass == 0 ? pw1 : pw2;
+                float* pb = pass == 0 ? pb1 : pb2;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) *reinterpret_cast<float4*>(pw + (prow * 9 + j) * C + c0) = acc[j];
+                *reinterpret_cast<float4*>(pb + prow * C + c0) = accb;
+            }
+        }
+    }
+}
+
 // dz[b,t,f,c] = silu'(z) * sum_{(to,dt),(fo,df): 2to+dt-1=t, 2fo+df-1=f} w[c,dt,df] * du[b,to,fo,c]
 __global__ __launch_bounds__(256) void dwconv2d_s2_dgrad_kernel(const float* __restrict__ z, const float* __restrict__ w,
                                                                  const float* __restrict__ du, float* __restrict__ dz,
@@ -645,6 +842,55 @@ extern "C" int dyn_conv2d_first_wgrad(const float* x, const float* dz, float* dw
     dyn::launch_reduce_partials(pw, dw, tiles, C * 9, beta, st);
     dyn::launch_reduce_partials(pb, dbias, tiles, C, beta, st);
     return dyn::check_launch("dyn_conv2d_first_wgrad");
+}
+
+// Fused first two subsampling stages (sub12_*_kernel above).  x [B, T, F] -> u2 [B, T2, F2, C], T1 = out_len(T), T2 = out_len(T1).
+extern "C" int dyn_sub12_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* u2, int64_t B,
+                             int64_t T, int64_t F, int64_t C, void* stream) {
+    DYN_REQUIRE(x && w1 && b1 && w2 && b2 && u2 && B >= 0 && T > 0 && F > 0 && C > 0, DYN_E_ARG, "dyn_sub12_fwd: bad arguments");
+    DYN_REQUIRE(C % 4 == 0 && ((((uintptr_t)u2) | ((uintptr_t)b1) | ((uintptr_t)b2)) & 15) == 0, DYN_E_UNSUPPORTED,
+                "dyn_sub12_fwd: needs C %% 4 == 0 and 16-byte aligned u2 / biases (use the unfused kernels otherwise)");
+    if (B == 0) return DYN_OK;
+    const int64_t T1 = (T - 1) / 2 + 1, F1 = (F - 1) / 2 + 1, T2 = (T1 - 1) / 2 + 1, F2 = (F1 - 1) / 2 + 1;
+    const int64_t rows = B * T2;
+    hipLaunchKernelGGL(sub12_fwd_kernel, dim3((unsigned)dyn::cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, w1, b1, w2, b2, u2, T,
+                       (int)F, T1, (int)F1, T2, (int)F2, (int)C, rows);
+    return dyn::check_launch("dyn_sub12_fwd");
+}
+
+extern "C" int64_t dyn_sub12_bwd_workspace_bytes(int64_t B, int64_t T, int64_t C) {
+    int64_t per;
+    const int64_t T1 = (T - 1) / 2 + 1;
+    const int64_t wgs = dyn::cdiv(wgrad_tiles2d(T1, &per) * B, 4);
+    return wgs * C * 20 * (int64_t)sizeof(float);
+}
+
+// dw1 [C, 3, 3], db1 [C], dw2 [C, 3, 3], db2 [C] = beta * (.) + the gradients of both stages, given du2 [B, T2, F2, C].
+extern "C" int dyn_sub12_bwd(const float* x, const float* du2, const float* w1, const float* b1, const float* w2, float* dw1, float* db1,
+                             float* dw2, float* db2, float beta, int64_t B, int64_t T, int64_t F, int64_t C, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+    DYN_REQUIRE(x && du2 && w1 && b1 && w2 && dw1 && db1 && dw2 && db2 && B >= 0 && T > 0 && F > 0 && C > 0, DYN_E_ARG,
+                "dyn_sub12_bwd: bad arguments");
+    DYN_REQUIRE(C % 4 == 0 && ((((uintptr_t)du2) | ((uintptr_t)b1)) & 15) == 0, DYN_E_UNSUPPORTED,
+                "dyn_sub12_bwd: needs C %% 4 == 0 and 16-byte aligned du2 / b1 (use the unfused kernels otherwise)");
+    if (B == 0) return DYN_OK;
+    const int64_t T1 = (T - 1) / 2 + 1, F1 = (F - 1) / 2 + 1, T2 = (T1 - 1) / 2 + 1, F2 = (F1 - 1) / 2 + 1;
+    int64_t per;
+    const int64_t chunks = wgrad_tiles2d(T1, &per), tiles = chunks * B, wgs = dyn::cdiv(tiles, 4);
+    DYN_REQUIRE(workspace && workspace_bytes >= wgs * C * 20 * (int64_t)sizeof(float) && (((uintptr_t)workspace) & 15) == 0, DYN_E_WORKSPACE,
+                "dyn_sub12_bwd: workspace too small");
+    float* pw1 = (float*)workspace;
+    float* pb1 = pw1 + wgs * C * 9;
+    float* pw2 = pb1 + wgs * C;
+    float* pb2 = pw2 + wgs * C * 9;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sub12_bwd_kernel, dim3((unsigned)wgs), dim3(256), 0, st, x, du2, w1, b1, w2, pw1, pb1, pw2, pb2, T, (int)F, T1, (int)F1,
+                       T2, (int)F2, (int)C, per, chunks, tiles);
+    dyn::launch_reduce_partials_taps(pw1, dw1, wgs, C * 9, beta, (int)C, st);
+    dyn::launch_reduce_partials(pb1, db1, wgs, C, beta, st);
+    dyn::launch_reduce_partials_taps(pw2, dw2, wgs, C * 9, beta, (int)C, st);
+    dyn::launch_reduce_partials(pb2, db2, wgs, C, beta, st);
+    return dyn::check_launch("dyn_sub12_bwd");
 }
 
 extern "C" int dyn_dwconv2d_s2_fwd(const float* z, const float* w, const float* bias, float* u, int64_t B, int64_t T,

@@ -159,6 +159,9 @@ class SCConformerXL:
         self._ctx_key = None
         self.fused_convmod = True   # GLU + dwconv + norm + SiLU in one kernel (csrc/convmod.hip)
         import os
+        # first two subsampling stages fused (csrc/conv.hip sub12_*): z1 = conv2d_first(x), the largest activation of the model, is
+        # recomputed from x in forward and backward instead of making four trips through HBM (DYN_FUSED_SUB=0: the separate kernels)
+        self.fused_subsampling = os.environ.get("DYN_FUSED_SUB", "1") != "0" and cfg["subsampling_conv_channels"] % 4 == 0
         # A/B switches (measurements only): DYN_FUSED_SILU=0 / DYN_GROUPED_WGRAD=0 restore the separate kernels / launches
         self.fused_silu = os.environ.get("DYN_FUSED_SILU", "0") != "0"        # SiLU / SiLU' in the epilogue of the producing GEMM: OFF
         # by default (A/B on one box, 3 chains: 739 vs 738 audio-s/s, while the GEMM's own rate drops 110 -> 101 TFLOP/s: the
@@ -300,7 +303,8 @@ class SCConformerXL:
             self._ctx_static = False
             return self._forward_eager(x)
         G = self._graphs
-        key = (tuple(x.shape), torch.is_grad_enabled(), self.fused_convmod, self.fused_attention, self.fused_silu, str(self.fused_attention_grad))
+        key = (tuple(x.shape), torch.is_grad_enabled(), self.fused_convmod, self.fused_attention, self.fused_silu, str(self.fused_attention_grad),
+               self.fused_subsampling)
         ent = G["fwd"].get(key)
         if ent is None:
             G["seen"][key] = G["seen"].get(key, 0) + 1
@@ -339,8 +343,12 @@ class SCConformerXL:
         for b in range(B):
             ops.transpose_ft(x[b], out=xt[b])
         # --- dw_striding x8 subsampling
-        z1 = ops.conv2d_first(xt, P["subsampling.conv1.weight"], P["subsampling.conv1.bias"])
-        u2 = ops.dwconv2d_s2(z1, P["subsampling.dw2.weight"], P["subsampling.dw2.bias"])
+        if self.fused_subsampling:
+            z1 = None
+            u2 = ops.sub12_fwd(xt, P["subsampling.conv1.weight"], P["subsampling.conv1.bias"], P["subsampling.dw2.weight"], P["subsampling.dw2.bias"])
+        else:
+            z1 = ops.conv2d_first(xt, P["subsampling.conv1.weight"], P["subsampling.conv1.bias"])
+            u2 = ops.dwconv2d_s2(z1, P["subsampling.dw2.weight"], P["subsampling.dw2.bias"])
         z2 = ops.linear(u2, P["subsampling.pw2.weight"], P["subsampling.pw2.bias"])
         u3 = ops.dwconv2d_s2(z2, P["subsampling.dw3.weight"], P["subsampling.dw3.bias"])
         if self.fused_silu:
@@ -420,8 +428,9 @@ class SCConformerXL:
             out = ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], beta=1.0, residual=h)
             lc["attn"] = (h, mean, rstd, n, qkv, lse, O)
             return out
-        if lc is None and self.fused_attention and D == 128 and B * H * ((T + 127) // 128) >= 320:
-            # no-grad pass with enough (batch, head, query-block) workgroups to fill the chip: fused kernel, scores stay on chip
+        if lc is None and self.fused_attention and D == 128 and (B * H * ((T + 127) // 128) >= 320 or T >= 512):
+            # no-grad pass: fused kernel, scores stay on chip.  Launches with too few (batch, head, query-block) workgroups to fill the
+            # chip split the keys over several workgroups (dyn_attention_fwd_split: B = 1 at T' = 2048 130 us against 299 us unsplit)
             O = ops.attention_fwd(qkv, B, T, H, D, 1.0 / math.sqrt(D))
             return ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], out=h, beta=1.0)
         S = torch.empty(B, H, T, T, device=h.device, dtype=torch.float32)
@@ -665,6 +674,14 @@ class SCConformerXL:
             ops.dwconv2d_s2_wgrad(z2, du3, G["subsampling.dw3.weight"], G["subsampling.dw3.bias"], beta=1.0)
         dz2 = ops.dwconv2d_s2_dgrad(z2, P["subsampling.dw3.weight"], du3)
         du2 = self._lin_bwd(dz2, u2, "subsampling.pw2.weight", "subsampling.pw2.bias")
+        if z1 is None and not input_grad:           # fused stages: z1 and dz1 are recomputed inside one kernel, never stored
+            if wg:
+                ops.sub12_bwd(xt, du2, P["subsampling.conv1.weight"], P["subsampling.conv1.bias"], P["subsampling.dw2.weight"],
+                              G["subsampling.conv1.weight"], G["subsampling.conv1.bias"], G["subsampling.dw2.weight"], G["subsampling.dw2.bias"],
+                              beta=1.0)
+            return None
+        if z1 is None:                              # the input gradient (entropy augmentation, lib.py:86-99) needs dz1 itself
+            z1 = ops.conv2d_first(xt, P["subsampling.conv1.weight"], P["subsampling.conv1.bias"])
         if wg:
             ops.dwconv2d_s2_wgrad(z1, du2, G["subsampling.dw2.weight"], G["subsampling.dw2.bias"], beta=1.0)
         dz1 = ops.dwconv2d_s2_dgrad(z1, P["subsampling.dw2.weight"], du2)

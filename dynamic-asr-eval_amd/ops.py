@@ -691,6 +691,29 @@ def dwconv2d_s2_wgrad(z, du, dw, dbias, beta=1.0):
                                      ws.data_ptr(), ws.numel(), _stream()), "dyn_dwconv2d_s2_wgrad")
 
 
+def sub12_fwd(x, w1, b1, w2, b2, out=None):
+    """Fused first two subsampling stages: x [B, T, F] -> u2 [B, T2, F2, C] = b2 + dw3x3_s2(silu(b1 + conv3x3_s2(x))); the
+    [B, T1, F1, C] intermediate never reaches HBM (dyn_sub12_fwd)."""
+    _cc(x, "sub12.x"); _cc(w1, "sub12.w1"); _cc(b1, "sub12.b1"); _cc(w2, "sub12.w2"); _cc(b2, "sub12.b2")
+    B, T, F = x.shape
+    C = w1.shape[0]
+    if out is None:
+        out = torch.empty(B, out_len(out_len(T)), out_len(out_len(F)), C, device=x.device, dtype=F32)
+    check(_L().dyn_sub12_fwd(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), out.data_ptr(), B, T, F, C, _stream()),
+          "dyn_sub12_fwd")
+    return out
+
+
+def sub12_bwd(x, du2, w1, b1, w2, dw1, db1, dw2, db2, beta=1.0):
+    """Weight / bias gradients of both fused stages from du2 [B, T2, F2, C] (z1 recomputed from x, dz1 never stored)."""
+    _cc(x, "sub12_bwd.x"); _cc(du2, "sub12_bwd.du2")
+    B, T, F = x.shape
+    C = w1.shape[0]
+    ws = workspace(x.device)
+    check(_L().dyn_sub12_bwd(x.data_ptr(), du2.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
+                             dw2.data_ptr(), db2.data_ptr(), beta, B, T, F, C, ws.data_ptr(), ws.numel(), _stream()), "dyn_sub12_bwd")
+
+
 def rotary(x, cos, sin, B, T, n_heads, D, row_stride, inverse=False):
     """In place on the first n_heads*D floats of every row_stride-float row of x."""
     _cc(x, "rotary.x"); _cc(cos, "rotary.cos"); _cc(sin, "rotary.sin")

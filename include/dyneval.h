@@ -179,6 +179,16 @@ int dyn_conv2d_first_dgrad(const float* dz, const float* w, float* dx, int64_t B
 int64_t dyn_conv2d_wgrad_workspace_bytes(int64_t B, int64_t To, int64_t C);
 int dyn_conv2d_first_wgrad(const float* x, const float* dz, float* dw, float* dbias, float beta, int64_t B, int64_t T,
                            int64_t F, int64_t C, void* workspace, int64_t workspace_bytes, void* stream);
+/* The first two subsampling stages FUSED: u2 = bias2 + dw3x3_s2(silu(bias1 + conv3x3_s2(x))), x [B, T, F] one channel ->
+ * u2 [B, T2, F2, C] (T1 = (T - 1) / 2 + 1, T2 = (T1 - 1) / 2 + 1, same for F).  The [B, T1, F1, C] intermediate (671 MB at B = 2,
+ * T = 16384: the largest activation of the model) and its gradient never exist: forward and backward recompute it from x
+ * (reference: upstream SCConformerXL `subsampling` reached through model(audio_signal=...) and loss.backward(), lcasr/lib.py:550,579).
+ * dyn_sub12_bwd accumulates dw1 [C, 3, 3], db1 [C], dw2 [C, 3, 3], db2 [C] (beta * old + new) from du2; deterministic. */
+int dyn_sub12_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* u2, int64_t B, int64_t T,
+                  int64_t F, int64_t C, void* stream);
+int64_t dyn_sub12_bwd_workspace_bytes(int64_t B, int64_t T, int64_t C);
+int dyn_sub12_bwd(const float* x, const float* du2, const float* w1, const float* b1, const float* w2, float* dw1, float* db1, float* dw2,
+                  float* db2, float beta, int64_t B, int64_t T, int64_t F, int64_t C, void* workspace, int64_t workspace_bytes, void* stream);
 int dyn_dwconv2d_s2_fwd(const float* z, const float* w, const float* bias, float* u, int64_t B, int64_t T, int64_t F,
                         int64_t C, void* stream);
 int dyn_dwconv2d_s2_dgrad(const float* z, const float* w, const float* du, float* dz, int64_t B, int64_t T, int64_t F,

@@ -27,6 +27,12 @@ for B in (2, 1):
                          ("conv2d_first wgrad", lambda: ops.conv2d_first_wgrad(x, dz1, dw, db, beta=0.0), GB(x, dz1))):
         us = timeit(fn)
         print(f"B={B} {name:20s} {us:8.1f} us  {gb/us*1e6/1e3:6.2f} TB/s algorithmic ({gb*1e3:.0f} MB)", flush=True)
+    # the same two stages fused (z1 / dz1 recomputed, never stored): forward replaces the first two lines, backward the last three
+    dw2 = torch.zeros(C, 3, 3, device=dev); db2 = torch.zeros(C, device=dev)
+    us = timeit(lambda: ops.sub12_fwd(x, w1, b1, w1, b1, out=u2))
+    print(f"B={B} {'sub12 fused fwd':20s} {us:8.1f} us  (reads {GB(x)*1e3:.0f} MB, writes {GB(u2)*1e3:.0f} MB)", flush=True)
+    us = timeit(lambda: ops.sub12_bwd(x, du2, w1, b1, w1, dw, db, dw2, db2, beta=0.0))
+    print(f"B={B} {'sub12 fused bwd':20s} {us:8.1f} us  (reads {GB(x, du2)*1e3:.0f} MB)", flush=True)
 for rows, C in ((2048, 768), (2048, 3072), (2048, 4096), (8192, 768)):
     x = torch.randn(rows, C, device=dev); out = torch.zeros(C, device=dev)
     us = timeit(lambda: ops.colsum(x, out, beta=1.0), n=50)

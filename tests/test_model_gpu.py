@@ -409,6 +409,35 @@ def test_chains_and_graphs_are_bit_identical_to_the_sequential_eager_loop(cuda):
     assert np.abs(plain - eager[0]).max() > 1e-6
 
 
+def test_fused_subsampling_matches_the_separate_kernels_through_the_model(cuda):
+    """model.fused_subsampling (default): forward bit-identical to the unfused path, every parameter gradient equal up to summation
+    order, and the input-gradient path (entropy augmentation: needs dz1 itself) still works from the fused forward."""
+    ref, hip = _pair(cuda, SMALL, vocab=128)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 80, 300, generator=g).to(cuda)
+    outs, grads, dxs = [], [], []
+    for fused in (True, False):
+        hip.fused_subsampling = fused
+        with torch.enable_grad():
+            out = hip(audio_signal=x)['final_posteriors']
+        gp = torch.randn(out.shape, generator=torch.Generator().manual_seed(13)).to(cuda) / out[0].numel()
+        hip.zero_grad()
+        dx = hip.backward(gp, input_grad=True)
+        outs.append(out.clone()); grads.append(hip.flat_grads.clone()); dxs.append(dx.clone())
+        with torch.enable_grad():
+            hip(audio_signal=x)
+        hip.zero_grad()
+        hip.backward(gp)
+        grads.append(hip.flat_grads.clone())
+    hip.fused_subsampling = True
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(dxs[0], dxs[1])
+    denom = grads[1].abs().max().item()
+    assert (grads[0] - grads[2]).abs().max().item() / denom < 1e-5       # input_grad=True runs the separate backward kernels in both modes
+    assert (grads[1] - grads[3]).abs().max().item() / denom < 1e-5       # fused backward vs separate backward
+    assert (grads[0] - grads[1]).abs().max().item() / denom < 1e-5
+
+
 def test_batch_renorm_eval_mode_parity(cuda):
     """conv_norm='batch_renorm': the loop runs the model in eval mode (reference lib.py:525), i.e. a per-channel affine
     with the checkpoint's running statistics.  Non-trivial statistics, forward + every parameter gradient vs the oracle,

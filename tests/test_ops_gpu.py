@@ -150,6 +150,38 @@ def test_subsampling_convs(cuda, T, Fq, C):
     _close(db, b2r.grad, 1e-3, "dwconv2d bgrad")
 
 
+@pytest.mark.parametrize("B,T,Fq,C", [(2, 64, 80, 256), (1, 37, 21, 96), (2, 1, 1, 32), (1, 5, 7, 8), (1, 9, 12, 516), (1, 1026, 80, 64)])
+def test_fused_first_two_subsampling_stages(cuda, B, T, Fq, C):
+    """dyn_sub12_fwd / dyn_sub12_bwd (conv3x3_s2 -> SiLU -> dw3x3_s2 with the intermediate recomputed, never stored) against torch's
+    conv2d chain + autograd, and against the unfused HIP kernels: the forward must be bit-identical to conv2d_first + dwconv2d_s2
+    (same accumulation order), the four gradients equal up to summation order.  Odd sizes exercise every padding / parity case."""
+    from dynamic_asr_eval_amd import ops
+    g = _g(300 + T + C)
+    x = torch.randn(B, T, Fq, generator=g)
+    w1, b1 = torch.randn(C, 3, 3, generator=g) * 0.5, torch.randn(C, generator=g) * 0.3
+    w2, b2 = torch.randn(C, 3, 3, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    w1r, b1r, w2r, b2r = (t.clone().requires_grad_() for t in (w1, b1, w2, b2))
+    z = F.conv2d(x.unsqueeze(1), w1r.unsqueeze(1), b1r, stride=2, padding=1)
+    u_ref = F.conv2d(F.silu(z), w2r.unsqueeze(1), b2r, stride=2, padding=1, groups=C)            # [B, C, T2, F2]
+    du = torch.randn(u_ref.shape, generator=g)
+    u_ref.backward(du)
+    xd, w1d, b1d, w2d, b2d = (t.to(cuda) for t in (x, w1, b1, w2, b2))
+    u = ops.sub12_fwd(xd, w1d, b1d, w2d, b2d)
+    assert tuple(u.shape) == (B, u_ref.shape[2], u_ref.shape[3], C)
+    _close(u, u_ref.permute(0, 2, 3, 1), 1e-4, "fused subsampling fwd")
+    unf = ops.dwconv2d_s2(ops.conv2d_first(xd, w1d, b1d), w2d, b2d)
+    assert torch.equal(u, unf), "fused forward must be bit-identical to the two separate kernels"
+    duc = du.permute(0, 2, 3, 1).contiguous().to(cuda)
+    dw1, db1, dw2, db2 = (torch.full(s_, 0.5, device=cuda) for s_ in ((C, 3, 3), (C,), (C, 3, 3), (C,)))
+    ops.sub12_bwd(xd, duc, w1d, b1d, w2d, dw1, db1, dw2, db2, beta=2.0)                        # beta: accumulates onto 2 * 0.5
+    scale = max(1.0, float(T * Fq) ** 0.5)
+    for got, want, name in ((dw1, w1r.grad, "dw1"), (db1, b1r.grad, "db1"), (dw2, w2r.grad, "dw2"), (db2, b2r.grad, "db2")):
+        _close(got - 1.0, want, 2e-5 * scale * max(1.0, want.abs().max().item()), "fused subsampling " + name)
+    again = [torch.full_like(t, 0.5) for t in (dw1, db1, dw2, db2)]
+    ops.sub12_bwd(xd, duc, w1d, b1d, w2d, *again, beta=2.0)
+    assert all(torch.equal(a, b) for a, b in zip(again, (dw1, db1, dw2, db2))), "deterministic"
+
+
 def test_rotary_roundtrip_and_reference(cuda):
     from dynamic_asr_eval_amd import ops
     B, T, H, D = 2, 50, 3, 128
