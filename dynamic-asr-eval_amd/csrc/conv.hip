@@ -579,7 +579,19 @@ __global__ __launch_bounds__(256) void sub12_bwd_kernel(const float* __restrict_
                 for (int dtx = 0; dtx < 3; ++dtx)
 #pragma unroll
                     for (int dfx = 0; dfx < 3; ++dfx) fma4s(z, wa[dtx * 3 + dfx], xv[dtx][dfx]);
-                const float4 sz = silu4(z), sg = silu_grad4(z);
+                float4 sz, sg;                      // silu(z) and silu'(z) from ONE sigmoid per element (same values as silu_f / silu_grad)
+                {
+                    const float zz[4] = {z.x, z.y, z.z, z.w};
+                    float a[4], d[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float sgm = dyn::sigmoidf_(zz[q]);
+                        a[q] = zz[q] * sgm;
+                        d[q] = sgm * (1.f + zz[q] * (1.f - sgm));
+                    }
+                    sz = make_float4(a[0], a[1], a[2], a[3]);
+                    sg = make_float4(d[0], d[1], d[2], d[3]);
+                }
                 float4 g = zero;
 #pragma unroll
                 for (int dt = 0; dt < 3; ++dt) {

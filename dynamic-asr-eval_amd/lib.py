@@ -290,6 +290,8 @@ def _dynamic_eval_gen(
     tgt_ring, tgt_turn = None, 0
     if native:
         model.use_graphs = bool(args.__dict__.get('use_graphs', True))   # hipGraph replay of the per-window launch sequences
+        # only the augmented copies are differentiated (lib.py:570-575): the clean copy's attention need not keep its probabilities
+        model.grad_samples = num_negatives if (skip_zero and _CLEAN_COPY_FUSED_ATTN) else None
     model.eval()  # don't update batchrenorm (reference lib.py:525)
     training_data, training_keys = prepare_chunks(spec_dev, seq_len, overlap)
     for epoch in range(args.__dict__.get('epochs', 1)):
@@ -435,6 +437,7 @@ def _dynamic_eval_gen(
     if native:
         model.flat_params.copy_(original_flat)
         model.frozen = frozen_before
+        model.grad_samples = None
     else:
         for p, p_orig in zip(model.parameters(), original_model_params):
             p.data = p_orig.data.to(p.device)
@@ -485,6 +488,9 @@ def _new_chain_stream(device, k):
     return torch.cuda.ExternalStream(out.value, device=device)
 
 
+import os as _os
+
+_CLEAN_COPY_FUSED_ATTN = _os.environ.get("DYN_CLEAN_FUSED_ATTN", "1") != "0"     # A/B switch
 _CHAIN_STREAMS = {}
 HOST_WAIT = [0.0]   # seconds the host spent blocked on the per-window pseudo-label ids (diagnostic)
 

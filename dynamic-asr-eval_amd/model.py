@@ -100,6 +100,24 @@ def _parse_fused_attn_grad(value):
     return mode
 
 
+class _no_gc:
+    """No cyclic garbage collection while a hipGraph is being captured: a collection that happens to run inside the capture can
+    finalise objects of an EARLIER model (its CUDAGraphs, their private memory pool), and freeing device memory / destroying a graph
+    from the capturing thread aborts the process ("Fatal Python error: Aborted ... Garbage-collecting" in the middle of a capture).
+    torch.cuda.graph collects once on entry; after that the collector stays off until the capture has ended."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 class _Group:
     """A named slice of the parameter list (`model.subsampling`, `model.layers[i]`, `model.decoder`): what the
     reference's freeze helpers iterate (reference lcasr/lib.py:163-204)."""
@@ -169,6 +187,10 @@ class SCConformerXL:
         self.grouped_wgrad = os.environ.get("DYN_GROUPED_WGRAD", "1") != "0"  # block weight gradients deferred to ONE grouped launch
                                                                               # at the end of the backward (+ bias column sums)
         self._wq = None
+        # Number of LEADING samples of a grad-mode batch whose activations the backward will need (None = all).  The dynamic-eval loss
+        # uses only the augmented copies (reference lcasr/lib.py:570-575; backward(n_active=...) below), so the clean copy's attention
+        # can take the fused no-grad kernel: its probabilities are never read again.  Set by lib.dynamic_eval around its loop.
+        self.grad_samples = None
         # grad-mode attention without the [B, H, T', T'] score matrix (forward keeps one log-sum-exp per row, the backward re-forms P
         # tile by tile: 7 products instead of 4): "0" never, "1" always, otherwise from T' >= this many frames
         self.fused_attention_grad = _parse_fused_attn_grad(os.environ.get("DYN_FUSED_ATTN_GRAD", "4096"))
@@ -304,7 +326,7 @@ class SCConformerXL:
             return self._forward_eager(x)
         G = self._graphs
         key = (tuple(x.shape), torch.is_grad_enabled(), self.fused_convmod, self.fused_attention, self.fused_silu, str(self.fused_attention_grad),
-               self.fused_subsampling)
+               self.fused_subsampling, self.grad_samples)
         ent = G["fwd"].get(key)
         if ent is None:
             G["seen"][key] = G["seen"].get(key, 0) + 1
@@ -319,7 +341,7 @@ class SCConformerXL:
             graph = torch.cuda.CUDAGraph()
             prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None      # no event records inside a capture
             try:
-                with torch.cuda.graph(graph, pool=G["pool"], capture_error_mode="thread_local"):
+                with _no_gc(), torch.cuda.graph(graph, pool=G["pool"], capture_error_mode="thread_local"):
                     out = self._forward_eager(static_in)
             finally:
                 ops.GEMM_PROFILE = prof
@@ -433,13 +455,20 @@ class SCConformerXL:
             # chip split the keys over several workgroups (dyn_attention_fwd_split: B = 1 at T' = 2048 130 us against 299 us unsplit)
             O = ops.attention_fwd(qkv, B, T, H, D, 1.0 / math.sqrt(D))
             return ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], out=h, beta=1.0)
-        S = torch.empty(B, H, T, T, device=h.device, dtype=torch.float32)
-        ops.gemm(qkv, qkv, S, trans_b=True, M=T, N=T, K=D, lda=3 * HD, ldb=3 * HD, ldc=T, nb1=B, nb2=H,
-                 sa=(T * 3 * HD, D), sb=(T * 3 * HD, D), sc=(H * T * T, T * T), b_off=HD, alpha=1.0 / math.sqrt(D))
-        ops.softmax(S, out=S)
+        # samples the backward will read the probabilities of: all, or (dynamic eval) only the leading augmented copies
+        Bs = B
+        if lc is not None and self.grad_samples is not None and self.fused_attention and D == 128 and T >= 512:
+            Bs = max(0, min(B, int(self.grad_samples)))
         O = torch.empty(B, T, HD, device=h.device, dtype=torch.float32)
-        ops.gemm(S, qkv, O, M=T, N=D, K=T, lda=T, ldb=3 * HD, ldc=HD, nb1=B, nb2=H, sa=(H * T * T, T * T),
-                 sb=(T * 3 * HD, D), sc=(T * HD, D), b_off=2 * HD)
+        S = torch.empty(Bs, H, T, T, device=h.device, dtype=torch.float32)
+        if Bs > 0:
+            ops.gemm(qkv, qkv, S, trans_b=True, M=T, N=T, K=D, lda=3 * HD, ldb=3 * HD, ldc=T, nb1=Bs, nb2=H,
+                     sa=(T * 3 * HD, D), sb=(T * 3 * HD, D), sc=(H * T * T, T * T), b_off=HD, alpha=1.0 / math.sqrt(D))
+            ops.softmax(S, out=S)
+            ops.gemm(S, qkv, O, M=T, N=D, K=T, lda=T, ldb=3 * HD, ldc=HD, nb1=Bs, nb2=H, sa=(H * T * T, T * T),
+                     sb=(T * 3 * HD, D), sc=(T * HD, D), b_off=2 * HD)
+        if Bs < B:      # the clean copies: scores stay on chip (key-split fused kernel), nothing kept for a backward
+            ops.attention_fwd(qkv[Bs:], B - Bs, T, H, D, 1.0 / math.sqrt(D), out=O[Bs:])
         if lc is not None:
             out = ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], beta=1.0, residual=h)
         else:
@@ -519,7 +548,7 @@ class SCConformerXL:
             graph = torch.cuda.CUDAGraph()
             prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
             try:
-                with torch.cuda.graph(graph, pool=G["pool"], capture_error_mode="thread_local"):
+                with _no_gc(), torch.cuda.graph(graph, pool=G["pool"], capture_error_mode="thread_local"):
                     self._backward(static_g, n_active, False)
             finally:
                 ops.GEMM_PROFILE = prof
@@ -613,6 +642,8 @@ class SCConformerXL:
         B, T, _ = h.shape
         scale = 1.0 / math.sqrt(D)
         dO = self._lin_bwd(dh, O, p + ".out.weight", p + ".out.bias")
+        if S.dim() == 4 and S.shape[0] < B:
+            raise ops.DynError(f"backward over {B} samples, but the forward kept the attention probabilities of {S.shape[0]} (model.grad_samples)")
         if S.dim() == 3:        # fused forward kept lse [B, H, T] instead of the probabilities
             dqkv = ops.attention_bwd(qkv, O, dO, S, B, T, H, D, scale)
             cos, sin = self._rotary(T)

@@ -438,6 +438,33 @@ def test_fused_subsampling_matches_the_separate_kernels_through_the_model(cuda):
     assert (grads[0] - grads[1]).abs().max().item() / denom < 1e-5
 
 
+def test_clean_copy_attention_through_the_fused_kernel(cuda):
+    """model.grad_samples = 1 (what lib.dynamic_eval sets: only the augmented copy is differentiated, reference lcasr/lib.py:570-575):
+    the clean copy's attention takes the fused no-grad kernel inside the grad-mode batch.  Same posteriors (fp32 summation order
+    apart), the same gradients for the augmented copy, and a backward over MORE samples than were kept is refused."""
+    from dynamic_asr_eval_amd import ops
+    ref, hip = _pair(cuda, SMALL, vocab=128)
+    x = torch.randn(2, 80, 4800, generator=torch.Generator().manual_seed(21)).to(cuda)          # T' = 600 >= 512: the fused kernel applies
+    res = []
+    for gs in (None, 1):
+        hip.grad_samples = gs
+        with torch.enable_grad():
+            out = hip(audio_signal=x)['final_posteriors']
+        gp = torch.randn(1, *out.shape[1:], generator=torch.Generator().manual_seed(22)).to(cuda) / out[0].numel()
+        hip.zero_grad()
+        hip.backward(gp, n_active=1)
+        res.append((out.clone(), hip.flat_grads.clone()))
+    # the augmented copy runs the same kernels either way, but as a batch of 1 instead of 2: another (tile, K-slice) plan may be
+    # chosen for its attention products, so equality is up to fp32 summation order
+    assert (res[0][0] - res[1][0]).abs().max().item() < 2e-5
+    assert (res[0][1] - res[1][1]).abs().max().item() / res[0][1].abs().max().item() < 1e-5
+    with torch.enable_grad():
+        out = hip(audio_signal=x)['final_posteriors']
+    with pytest.raises(ops.DynError):
+        hip.backward(torch.zeros_like(out))
+    hip.grad_samples = None
+
+
 def test_batch_renorm_eval_mode_parity(cuda):
     """conv_norm='batch_renorm': the loop runs the model in eval mode (reference lib.py:525), i.e. a per-channel affine
     with the checkpoint's running statistics.  Non-trivial statistics, forward + every parameter gradient vs the oracle,
