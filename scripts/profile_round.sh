@@ -7,7 +7,7 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 B="$root/bench.py"
-common="--warmup 0 --no_cpu_baseline --side_steps 0"
+common="--warmup 0 --no_cpu_baseline --side_steps 0 --side_workloads 0"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$out/c1" -o p -- python3 "$B" --steps 2 --prewarm_s 10 --chains 1 $common > "$out/c1.json" 2> "$out/c1.err" && echo "c1 done" \
 && rocprofv3 --output-format csv --kernel-trace --stats -d "$out/c3" -o p -- python3 "$B" --steps 3 --prewarm_s 10 $common > "$out/c3.json" 2> "$out/c3.err" && echo "c3 done" \
 && rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$out/fetch" -o p -- python3 "$B" --steps 1 --seconds 300 --prewarm_s 0 --graphs 0 --chains 1 $common > "$out/fetch.json" 2> "$out/fetch.err" && echo "fetch done" \
@@ -16,6 +16,7 @@ rocprofv3 --output-format csv --kernel-trace --stats -d "$out/c1" -o p -- python
 cd "$root"
 mkdir -p "$out/summary"
 for c in c1 c3; do f=$(find "$out/$c" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/summary/${tag}_kernel_stats_$c.csv"; done
+python3 scripts/trace_overlap.py "$out/c3" "$out/summary/${tag}_trace_overlap_chains3.json" > "$out/summary/overlap.log" 2>&1
 python3 scripts/pmc_summary.py "$out/fetch" "$out/write" "$out/summary/${tag}_gemm_traffic.json" > "$out/summary/pmc_summary.log" 2>&1
 python3 scripts/pmc_mfma_util.py "$(dirname $(find $out/mfma -name '*kernel_trace.csv' | head -1))" "$out/summary/${tag}_gemm_mfma_util.json" > "$out/summary/mfma.log" 2>&1
 python3 scripts/pmc_hbm_kernels.py "$out/fetch" "$out/write" "$out/summary/${tag}_hbm_kernels.json" > "$out/summary/hbm.log" 2>&1
