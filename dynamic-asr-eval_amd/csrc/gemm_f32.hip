@@ -693,6 +693,18 @@ Plan make_plan(const dyn_gemm_desc* d) {
         return best;
     }
     const int64_t batch = d->nb1 * d->nb2;
+    // Experiment switch (DYN_GEMM_BIGTILE=1, measurements only): the largest tile that fits the output, no tail slicing, no split-K
+    // unless the output is tiny — the plan for a GPU shared by MANY recording chains, where a launch need not fill the chip by
+    // itself because the workgroups of the other chains' GEMMs occupy the remaining slots.
+    static const bool big = [] { const char* e = getenv("DYN_GEMM_BIGTILE"); return e && atoi(e) != 0; }();
+    if (big && d->split_k == 0) {
+        const int bm = d->M >= 128 ? 128 : 64, bn = d->N >= 128 ? 128 : 64;
+        const int64_t tiles = dyn::cdiv(d->M, bm) * dyn::cdiv(d->N, bn) * batch;
+        int split = 1;
+        if (tiles < 64 && d->K >= 4096) split = (int)(tiles < 8 ? 12 : 4);     // the deep-K subsampling weight gradients
+        eval_config(d, bm, bn, split, 1, &best, &cost);
+        return best;
+    }
     if (d->split_k == 0) {
         for (int i = 0; i < kNumTuned; ++i) {
             const Tuned& t = kTuned[i];

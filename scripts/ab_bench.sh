@@ -9,7 +9,8 @@ python bench.py --steps 3 --warmup 0 --prewarm_s 30 --no_cpu_baseline --side_ste
 for r in $(seq 1 $ROUNDS); do
   for cfg in "$@"; do
     name=${cfg%%:*}; envs=${cfg#*:}
-    ( for e in ${envs//,/ }; do export "$e"; done; python bench.py $ARGS > "$out/${name}_$r.json" 2> "$out/${name}_$r.err" )
+    # BENCH_EXTRA=--chains@6@--steps@6 in a config adds bench.py arguments for that config (@ = space)
+    ( for e in ${envs//,/ }; do export "$e"; done; python bench.py $ARGS ${BENCH_EXTRA//@/ } > "$out/${name}_$r.json" 2> "$out/${name}_$r.err" )
     python - "$out/${name}_$r.json" "$name" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
