@@ -410,6 +410,7 @@ extern "C" int dyn_ctc_loss(const float* log_probs, int64_t T, int64_t B, int64_
                 DYN_E_ARG, "dyn_ctc_loss: bad arguments");
     const int64_t Sm = S_max > 0 ? S_max : 1;
     const int64_t L = 2 * Sm + 1;
+    // also bounds the dynamic LDS of ctc_prep_kernel (S_max * 4 bytes <= 16 KB) and of the scan (2 * L floats <= 64 KB)
     DYN_REQUIRE(L <= 8 * SCAN_T, DYN_E_UNSUPPORTED, "dyn_ctc_loss: lattice width %lld > %d unsupported", (long long)L, 8 * SCAN_T);
     CtcWs w = carve(workspace, T, B, Sm);
     DYN_REQUIRE(workspace && workspace_bytes >= w.total, DYN_E_WORKSPACE, "dyn_ctc_loss: workspace %lld < %lld bytes",
