@@ -47,6 +47,12 @@ def load():
             f"{LIB_PATH} not found: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C dynamic-asr-eval_amd/csrc`). "
             "There is no CPU fallback for the product path.")
+    # Load order matters: PyTorch-ROCm ships its OWN HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) and this library
+    # is linked against the same SONAME.  With torch imported first the loader binds libdyneval_hip.so to torch's runtime — one HIP
+    # runtime in the process, torch's streams and allocations are valid in our launches.  Loaded first, the system runtime under
+    # /opt/rocm comes in as well and every launch from here fails with "no ROCm-capable device is detected" (seen with build()
+    # followed by smoke() in one process).  The host side is PyTorch-based anyway (memory, streams), so import it here.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in prototypes().items():
         fn = getattr(lib, name)  # AttributeError here = header and library out of sync: fail loudly
