@@ -243,8 +243,9 @@ __device__ __forceinline__ void read_frag_glds(const float* __restrict__ s, int 
 
 // One output tile (or one K slice of it) by one 256-thread workgroup.  `bid` = position of this workgroup among the launch's work
 // items (the single-GEMM kernel passes blockIdx.x; the grouped kernel passes the index inside the group, already remapped).
-template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, bool GROUPED>
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, bool GROUPED, int STAGES = 2>
 __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, float* smem) {
+    static_assert(STAGES == 2 || (STAGES == 3 && GLDS), "the three-stage pipeline exists for the direct-to-LDS path only");
     constexpr bool AK = !TA;  // A has K contiguous in HBM
     constexpr bool BKM = TB;  // B has K contiguous in HBM
     constexpr int WTM = BM / 64, WTN = BN / 64;  // 32x32 tiles per wave along M / N
@@ -315,10 +316,12 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
     };
     GldsStager<AK, BM> stA;
     GldsStager<BKM, BN> stB;
+    constexpr int NDMA = GLDS ? GldsStager<AK, BM>::NI + GldsStager<BKM, BN>::NI : 0;   // LDS-DMA instructions per wave per K tile
     if (GLDS) {
         stA.init(A, p.lda, m0, p.M, kbeg, wave, lane);
         stB.init(B, p.ldb, n0, p.N, kbeg, wave, lane);
         if (nk > 0) { stA.issue(smem, wave); stB.issue(smem + SA, wave); }
+        if (STAGES == 3 && nk > 1) { stA.issue(smem + (SA + SB), wave); stB.issue(smem + (SA + SB) + SA, wave); }
     } else if (nk > 0) {
         fetch(kbeg);
         store_tile<AK, BM>(smem, ra);
@@ -326,7 +329,11 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
     }
     // An LDS-DMA is ordered for a ds_read only by the issuing wave's vmcnt wait followed by a barrier: state the wait explicitly
     // instead of relying on the fence hipcc attaches to __syncthreads().
-    if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // three stages: tile 1 may stay in flight (LDS-DMAs retire in issue order: all but the NDMA youngest = tile 0 has landed)
+    if (GLDS) {
+        if (STAGES == 3 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     // Main loop, software-pipelined at two levels so a wave's MFMA stream never waits on LDS latency:
@@ -376,8 +383,17 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
         const float* sa = smem + cur * (SA + SB);
         const float* sb = sa + SA;
         const bool more = kt + 1 < nk;
-        float* da = smem + (cur ^ 1) * (SA + SB);
-        if (GLDS) {
+        const int nxt = STAGES == 3 ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
+        float* da = smem + nxt * (SA + SB);
+        const bool more2 = STAGES == 3 && kt + 2 < nk;
+        if (GLDS && STAGES == 3) {
+            // tile kt+2 goes into the stage that held tile kt-1: its last fragment reads were waited for before the previous barrier.
+            // The load then has TWO K tiles of MFMAs to land under (the 64-row tiles have only 16 MFMAs per wave between barriers).
+            if (more2) {
+                float* d2 = smem + (nxt == 2 ? 0 : nxt + 1) * (SA + SB);
+                stA.issue(d2, wave); stB.issue(d2 + SA, wave);
+            }
+        } else if (GLDS) {
             // the other buffer is free: its last fragment reads were waited for before the previous barrier
             if (more) { stA.issue(da, wave); stB.issue(da + SA, wave); }
         } else if (more) {
@@ -396,13 +412,16 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
             store_tile<AK, BM>(da, ra);
             store_tile<BKM, BN>(da + SA, rb);
         }
-        if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of tile kt+1 has landed (see the prologue)
+        if (GLDS) {   // this wave's part of tile kt+1 has landed (see the prologue); with three stages tile kt+2 stays in flight
+            if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         if (more) read_chunk(da, da + SA, 0, 0);
         mfma_chunk((NC - 1) & 1);
         __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * WTM * WTN, 0);
-        cur ^= 1;
+        cur = nxt;
     }
 
     if (GROUPED && do_colsum) {   // lane halves hold the two k sub-ranges of every chunk: fold them, then lanes h == 0 own row i
@@ -537,11 +556,11 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #ifndef DYN_GEMM_WAVES_PER_EU
 #define DYN_GEMM_WAVES_PER_EU 2
 #endif
-template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS>
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, int STAGES = 2>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DYN_GEMM_WAVES_PER_EU, 8))) void gemm_f32_kernel(const KParams p) {
     constexpr int SA = GLDS ? BM * BK : BM * LDK, SB = GLDS ? BN * BK : BN * LDK;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
-    gemm_tile<TA, TB, BM, BN, VEC, GLDS, false>(p, (int64_t)blockIdx.x, smem);
+    __shared__ __attribute__((aligned(16))) float smem[STAGES * (SA + SB)];
+    gemm_tile<TA, TB, BM, BN, VEC, GLDS, false, STAGES>(p, (int64_t)blockIdx.x, smem);
 }
 
 // Grouped launch: ONE grid over the tiles of up to kMaxGroups independent GEMMs that share (TA, TB) and the tile shape (the
@@ -740,6 +759,13 @@ void launch_vec(const KParams& kp, bool vec, dim3 grid, hipStream_t st) {
     static const bool allow_glds = [] { const char* e = getenv("DYN_GEMM_GLDS"); return !e || atoi(e) != 0; }();
     const bool glds = allow_glds && vec && kp.K % BK == 0 && kp.K > 0 && (!TA || kp.M % 4 == 0) && (TB || kp.N % 4 == 0) &&
                       (!TA || kp.M >= 4) && (TB || kp.N >= 4);
+    // Experiment switch (DYN_GEMM_STAGES3=1: 64x64 tiles, =2: also 64x128 / 128x64): a third LDS stage for the small tiles, whose waves
+    // spend 0.14 - 0.20 of their cycles parked at the once-per-K-tile load wait (profiles/r03_gemm_sq_counters_by_tile.txt)
+    static const int stages3 = [] { const char* e = getenv("DYN_GEMM_STAGES3"); return e ? atoi(e) : 0; }();
+    constexpr bool small = BM * BN <= 64 * 64, mid = BM * BN == 64 * 128;
+    if (glds && ((small && stages3 >= 1) || (mid && stages3 >= 2))) {
+        if constexpr (small || mid) { hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true, 3>), grid, dim3(NTHREADS), 0, st, kp); return; }
+    }
     if (glds) hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true>), grid, dim3(NTHREADS), 0, st, kp);
     else if (vec) hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, false>), grid, dim3(NTHREADS), 0, st, kp);
     else hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, false, false>), grid, dim3(NTHREADS), 0, st, kp);
