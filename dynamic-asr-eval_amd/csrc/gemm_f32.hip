@@ -243,8 +243,9 @@ __device__ __forceinline__ void read_frag_glds(const float* __restrict__ s, int 
 
 // One output tile (or one K slice of it) by one 256-thread workgroup.  `bid` = position of this workgroup among the launch's work
 // items (the single-GEMM kernel passes blockIdx.x; the grouped kernel passes the index inside the group, already remapped).
-template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, bool GROUPED, int STAGES = 2>
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, bool GROUPED, int STAGES = 2, bool DUAL = false>
 __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, float* smem) {
+    static_assert(!DUAL || (BM == 64 && BN == 64), "the two-chain accumulation is an experiment for the 64x64 tile (one 32x32 MFMA tile per wave)");
     static_assert(STAGES == 2 || (STAGES == 3 && GLDS), "the three-stage pipeline exists for the direct-to-LDS path only");
     constexpr bool AK = !TA;  // A has K contiguous in HBM
     constexpr bool BKM = TB;  // B has K contiguous in HBM
@@ -302,6 +303,11 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
         for (int b = 0; b < WTN; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    // DUAL (experiment, DYN_GEMM_DUALACC): the 64x64 tile gives a wave ONE 32x32 accumulator, i.e. one chain of dependent MFMAs; with a second
+    // accumulator the odd k-pairs form an independent chain (summed into the first at the end: another rounding order than the other tiles)
+    f32x16 acc2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
 
     float4 ra[BM * BK / 1024], rb[BN * BK / 1024];
     const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N);  // workgroup-uniform
@@ -369,6 +375,14 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #pragma unroll
             for (int a = 0; a < WTM; ++a) csum[a] += (fa[slot][a][0] + fa[slot][a][1]) + (fa[slot][a][2] + fa[slot][a][3]);
         }
+        if (DUAL) {
+#pragma unroll
+            for (int s = 0; s < 4; s += 2) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0][s], fb[slot][0][s], acc[0][0], 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0][s + 1], fb[slot][0][s + 1], acc2, 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -424,6 +438,10 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
         cur = nxt;
     }
 
+    if (DUAL) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
+    }
     if (GROUPED && do_colsum) {   // lane halves hold the two k sub-ranges of every chunk: fold them, then lanes h == 0 own row i
 #pragma unroll
         for (int a = 0; a < WTM; ++a) {
@@ -556,11 +574,11 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #ifndef DYN_GEMM_WAVES_PER_EU
 #define DYN_GEMM_WAVES_PER_EU 2
 #endif
-template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, int STAGES = 2>
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, int STAGES = 2, bool DUAL = false>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DYN_GEMM_WAVES_PER_EU, 8))) void gemm_f32_kernel(const KParams p) {
     constexpr int SA = GLDS ? BM * BK : BM * LDK, SB = GLDS ? BN * BK : BN * LDK;
     __shared__ __attribute__((aligned(16))) float smem[STAGES * (SA + SB)];
-    gemm_tile<TA, TB, BM, BN, VEC, GLDS, false, STAGES>(p, (int64_t)blockIdx.x, smem);
+    gemm_tile<TA, TB, BM, BN, VEC, GLDS, false, STAGES, DUAL>(p, (int64_t)blockIdx.x, smem);
 }
 
 // Grouped launch: ONE grid over the tiles of up to kMaxGroups independent GEMMs that share (TA, TB) and the tile shape (the
@@ -763,6 +781,10 @@ void launch_vec(const KParams& kp, bool vec, dim3 grid, hipStream_t st) {
     // spend 0.14 - 0.20 of their cycles parked at the once-per-K-tile load wait (profiles/r03_gemm_sq_counters_by_tile.txt)
     static const int stages3 = [] { const char* e = getenv("DYN_GEMM_STAGES3"); return e ? atoi(e) : 0; }();
     constexpr bool small = BM * BN <= 64 * 64, mid = BM * BN == 64 * 128;
+    static const bool dualacc = [] { const char* e = getenv("DYN_GEMM_DUALACC"); return e && atoi(e) != 0; }();
+    if (glds && small && dualacc) {
+        if constexpr (small) { hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true, 2, true>), grid, dim3(NTHREADS), 0, st, kp); return; }
+    }
     if (glds && ((small && stages3 >= 1) || (mid && stages3 >= 2))) {
         if constexpr (small || mid) { hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true, 3>), grid, dim3(NTHREADS), 0, st, kp); return; }
     }
