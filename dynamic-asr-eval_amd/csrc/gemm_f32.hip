@@ -243,7 +243,9 @@ __device__ __forceinline__ void read_frag_glds(const float* __restrict__ s, int 
 
 // One output tile (or one K slice of it) by one 256-thread workgroup.  `bid` = position of this workgroup among the launch's work
 // items (the single-GEMM kernel passes blockIdx.x; the grouped kernel passes the index inside the group, already remapped).
-template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, bool GROUPED, int STAGES = 2, bool DUAL = false>
+// DBG (diagnostic builds of the 64x64 kernel only, results are garbage by construction; DYN_GEMM_DEBUG): 1 = no direct-to-LDS loads inside the K loop
+// (MFMA + LDS reads + barrier alone), 2 = no workgroup barrier inside the K loop (MFMA + LDS reads + loads)
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, bool GROUPED, int STAGES = 2, bool DUAL = false, int DBG = 0>
 __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, float* smem) {
     static_assert(!DUAL || (BM == 64 && BN == 64), "the two-chain accumulation is an experiment for the 64x64 tile (one 32x32 MFMA tile per wave)");
     static_assert(STAGES == 2 || (STAGES == 3 && GLDS), "the three-stage pipeline exists for the direct-to-LDS path only");
@@ -409,7 +411,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
             }
         } else if (GLDS) {
             // the other buffer is free: its last fragment reads were waited for before the previous barrier
-            if (more) { stA.issue(da, wave); stB.issue(da + SA, wave); }
+            if (more && DBG != 1) { stA.issue(da, wave); stB.issue(da + SA, wave); }
         } else if (more) {
             fetch(kbeg + (int64_t)(kt + 1) * BK);
         }
@@ -430,7 +432,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
             if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();
+        if (DBG != 2) __syncthreads();
         if (more) read_chunk(da, da + SA, 0, 0);
         mfma_chunk((NC - 1) & 1);
         __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
@@ -574,11 +576,11 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #ifndef DYN_GEMM_WAVES_PER_EU
 #define DYN_GEMM_WAVES_PER_EU 2
 #endif
-template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, int STAGES = 2, bool DUAL = false>
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, int STAGES = 2, bool DUAL = false, int DBG = 0>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DYN_GEMM_WAVES_PER_EU, 8))) void gemm_f32_kernel(const KParams p) {
     constexpr int SA = GLDS ? BM * BK : BM * LDK, SB = GLDS ? BN * BK : BN * LDK;
     __shared__ __attribute__((aligned(16))) float smem[STAGES * (SA + SB)];
-    gemm_tile<TA, TB, BM, BN, VEC, GLDS, false, STAGES, DUAL>(p, (int64_t)blockIdx.x, smem);
+    gemm_tile<TA, TB, BM, BN, VEC, GLDS, false, STAGES, DUAL, DBG>(p, (int64_t)blockIdx.x, smem);
 }
 
 // Grouped launch: ONE grid over the tiles of up to kMaxGroups independent GEMMs that share (TA, TB) and the tile shape (the
@@ -781,7 +783,12 @@ void launch_vec(const KParams& kp, bool vec, dim3 grid, hipStream_t st) {
     // spend 0.14 - 0.20 of their cycles parked at the once-per-K-tile load wait (profiles/r03_gemm_sq_counters_by_tile.txt)
     static const int stages3 = [] { const char* e = getenv("DYN_GEMM_STAGES3"); return e ? atoi(e) : 0; }();
     constexpr bool small = BM * BN <= 64 * 64, mid = BM * BN == 64 * 128;
-    static const bool dualacc = [] { const char* e = getenv("DYN_GEMM_DUALACC"); return e && atoi(e) != 0; }();
+    static const int dbg = [] { const char* e = getenv("DYN_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
+    if constexpr (small && !TA && TB) {      // diagnostic builds: NT 64x64 only
+        if (glds && dbg == 1) { hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true, 2, false, 1>), grid, dim3(NTHREADS), 0, st, kp); return; }
+        if (glds && dbg == 2) { hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true, 2, false, 2>), grid, dim3(NTHREADS), 0, st, kp); return; }
+    }
+    static const bool dualacc = [] { const char* e = getenv("DYN_GEMM_DEBUG_UNUSED"); (void)e; const char* f = getenv("DYN_GEMM_DUALACC"); return f && atoi(f) != 0; }();
     if (glds && small && dualacc) {
         if constexpr (small) { hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true, 2, true>), grid, dim3(NTHREADS), 0, st, kp); return; }
     }
