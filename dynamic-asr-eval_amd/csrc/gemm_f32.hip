@@ -23,6 +23,7 @@
 //     round of workgroups is K-sliced the same way (tail slicing): deterministic, no float atomics.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -228,6 +229,10 @@ struct GldsStager {
             ptr[j] += step;
         }
     }
+    __device__ __forceinline__ void issue_piece(float* tile, int wave, int j) {     // j must be a compile-time constant after unrolling
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)ptr[j], (lds_void_t*)(tile + (wave * NI + j) * 256), 16, 0, 0);
+        ptr[j] += step;
+    }
 };
 
 template <bool KMAJOR, int R>
@@ -245,8 +250,12 @@ __device__ __forceinline__ void read_frag_glds(const float* __restrict__ s, int 
 // items (the single-GEMM kernel passes blockIdx.x; the grouped kernel passes the index inside the group, already remapped).
 // DBG (diagnostic builds of the 64x64 kernel only, results are garbage by construction; DYN_GEMM_DEBUG): 1 = no direct-to-LDS loads inside the K loop
 // (MFMA + LDS reads + barrier alone), 2 = no workgroup barrier inside the K loop (MFMA + LDS reads + loads)
-template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, bool GROUPED, int STAGES = 2, bool DUAL = false, int DBG = 0>
+// SPREAD (experiment, DYN_GEMM_SPREAD): the direct-to-LDS loads of tile kt+1 are issued ONE PER CHUNK between the MFMAs of tile kt instead of in one
+// bunch at the top of the iteration (an LDS-DMA issued next to a batch of LDS reads costs the wave 100-185 cycles, among MFMAs ~60; a diagnostic build
+// without the loads runs the 64x64 K loop 17-21 % faster).  The last iteration is peeled so the issue is unconditional inside the scheduling region.
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, bool GROUPED, int STAGES = 2, bool DUAL = false, int DBG = 0, bool SPREAD = false>
 __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, float* smem) {
+    static_assert(!SPREAD || (GLDS && STAGES == 2), "spread loads: direct-to-LDS path with two stages");
     static_assert(!DUAL || (BM == 64 && BN == 64), "the two-chain accumulation is an experiment for the 64x64 tile (one 32x32 MFMA tile per wave)");
     static_assert(STAGES == 2 || (STAGES == 3 && GLDS), "the three-stage pipeline exists for the direct-to-LDS path only");
     constexpr bool AK = !TA;  // A has K contiguous in HBM
@@ -395,6 +404,46 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
     };
     int cur = 0;
     if (nk > 0) read_chunk(smem, smem + SA, 0, 0);
+    if constexpr (SPREAD) {
+        constexpr int NA = GldsStager<AK, BM>::NI, NB = GldsStager<BKM, BN>::NI, NP = NA + NB;
+        auto body = [&](auto issue_tag) {
+            constexpr bool ISSUE = decltype(issue_tag)::value;
+            const float* sa = smem + cur * (SA + SB);
+            const float* sb = sa + SA;
+            float* da = smem + (cur ^ 1) * (SA + SB);
+            static_assert(NC == 4, "the spread schedule is written for four k-chunks per tile");
+            auto chunk = [&](auto c_tag) {
+                constexpr int c = decltype(c_tag)::value;
+                read_chunk(sa, sb, c + 1, (c + 1) & 1);
+                // pieces c, c + 3, c + 6 of tile kt+1 ride in this chunk, right behind its first MFMA
+                constexpr int per = (NP - c + 2) / 3;                  // how many of the NP pieces have index = c (mod 3)
+                if constexpr (ISSUE) {
+#pragma unroll
+                    for (int q = 0; q < per; ++q) {
+                        const int j = c + 3 * q;
+                        if (j < NA) stA.issue_piece(da, wave, j); else stB.issue_piece(da + SA, wave, j - NA);
+                    }
+                }
+                mfma_chunk(c & 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (ISSUE && per > 0) __builtin_amdgcn_sched_group_barrier(0x020, per, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * WTM * WTN - 1, 0);
+            };
+            chunk(std::integral_constant<int, 0>{});
+            chunk(std::integral_constant<int, 1>{});
+            chunk(std::integral_constant<int, 2>{});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (ISSUE) read_chunk(da, da + SA, 0, 0);
+            mfma_chunk((NC - 1) & 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * WTM * WTN, 0);
+            cur ^= 1;
+        };
+        for (int kt = 0; kt + 1 < nk; ++kt) body(std::true_type{});
+        if (nk > 0) body(std::false_type{});
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         const float* sa = smem + cur * (SA + SB);
         const float* sb = sa + SA;
@@ -576,11 +625,11 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #ifndef DYN_GEMM_WAVES_PER_EU
 #define DYN_GEMM_WAVES_PER_EU 2
 #endif
-template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, int STAGES = 2, bool DUAL = false, int DBG = 0>
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, int STAGES = 2, bool DUAL = false, int DBG = 0, bool SPREAD = false>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DYN_GEMM_WAVES_PER_EU, 8))) void gemm_f32_kernel(const KParams p) {
     constexpr int SA = GLDS ? BM * BK : BM * LDK, SB = GLDS ? BN * BK : BN * LDK;
     __shared__ __attribute__((aligned(16))) float smem[STAGES * (SA + SB)];
-    gemm_tile<TA, TB, BM, BN, VEC, GLDS, false, STAGES, DUAL, DBG>(p, (int64_t)blockIdx.x, smem);
+    gemm_tile<TA, TB, BM, BN, VEC, GLDS, false, STAGES, DUAL, DBG, SPREAD>(p, (int64_t)blockIdx.x, smem);
 }
 
 // Grouped launch: ONE grid over the tiles of up to kMaxGroups independent GEMMs that share (TA, TB) and the tile shape (the
@@ -783,6 +832,11 @@ void launch_vec(const KParams& kp, bool vec, dim3 grid, hipStream_t st) {
     // spend 0.14 - 0.20 of their cycles parked at the once-per-K-tile load wait (profiles/r03_gemm_sq_counters_by_tile.txt)
     static const int stages3 = [] { const char* e = getenv("DYN_GEMM_STAGES3"); return e ? atoi(e) : 0; }();
     constexpr bool small = BM * BN <= 64 * 64, mid = BM * BN == 64 * 128;
+    static const int spread = [] { const char* e = getenv("DYN_GEMM_SPREAD"); return e ? atoi(e) : 0; }();     // 1: 64-row tiles, 2: every tile
+    if (glds && (spread >= 2 || (spread == 1 && BM * BN <= 64 * 128))) {
+        hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true, 2, false, 0, true>), grid, dim3(NTHREADS), 0, st, kp);
+        return;
+    }
     static const int dbg = [] { const char* e = getenv("DYN_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
     if constexpr (small && !TA && TB) {      // diagnostic builds: NT 64x64 only
         if (glds && dbg == 1) { hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true, 2, false, 1>), grid, dim3(NTHREADS), 0, st, kp); return; }
