@@ -23,7 +23,6 @@
 //     round of workgroups is K-sliced the same way (tail slicing): deterministic, no float atomics.
 #include "common.h"
 #include <cstdlib>
-#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -229,10 +228,6 @@ struct GldsStager {
             ptr[j] += step;
         }
     }
-    __device__ __forceinline__ void issue_piece(float* tile, int wave, int j) {     // j must be a compile-time constant after unrolling
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)ptr[j], (lds_void_t*)(tile + (wave * NI + j) * 256), 16, 0, 0);
-        ptr[j] += step;
-    }
 };
 
 template <bool KMAJOR, int R>
@@ -248,16 +243,8 @@ __device__ __forceinline__ void read_frag_glds(const float* __restrict__ s, int 
 
 // One output tile (or one K slice of it) by one 256-thread workgroup.  `bid` = position of this workgroup among the launch's work
 // items (the single-GEMM kernel passes blockIdx.x; the grouped kernel passes the index inside the group, already remapped).
-// DBG (diagnostic builds of the 64x64 kernel only, results are garbage by construction; DYN_GEMM_DEBUG): 1 = no direct-to-LDS loads inside the K loop
-// (MFMA + LDS reads + barrier alone), 2 = no workgroup barrier inside the K loop (MFMA + LDS reads + loads)
-// SPREAD (experiment, DYN_GEMM_SPREAD): the direct-to-LDS loads of tile kt+1 are issued ONE PER CHUNK between the MFMAs of tile kt instead of in one
-// bunch at the top of the iteration (an LDS-DMA issued next to a batch of LDS reads costs the wave 100-185 cycles, among MFMAs ~60; a diagnostic build
-// without the loads runs the 64x64 K loop 17-21 % faster).  The last iteration is peeled so the issue is unconditional inside the scheduling region.
-template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, bool GROUPED, int STAGES = 2, bool DUAL = false, int DBG = 0, bool SPREAD = false>
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, bool GROUPED>
 __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, float* smem) {
-    static_assert(!SPREAD || (GLDS && STAGES == 2), "spread loads: direct-to-LDS path with two stages");
-    static_assert(!DUAL || (BM == 64 && BN == 64), "the two-chain accumulation is an experiment for the 64x64 tile (one 32x32 MFMA tile per wave)");
-    static_assert(STAGES == 2 || (STAGES == 3 && GLDS), "the three-stage pipeline exists for the direct-to-LDS path only");
     constexpr bool AK = !TA;  // A has K contiguous in HBM
     constexpr bool BKM = TB;  // B has K contiguous in HBM
     constexpr int WTM = BM / 64, WTN = BN / 64;  // 32x32 tiles per wave along M / N
@@ -314,11 +301,6 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
         for (int b = 0; b < WTN; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    // DUAL (experiment, DYN_GEMM_DUALACC): the 64x64 tile gives a wave ONE 32x32 accumulator, i.e. one chain of dependent MFMAs; with a second
-    // accumulator the odd k-pairs form an independent chain (summed into the first at the end: another rounding order than the other tiles)
-    f32x16 acc2;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
 
     float4 ra[BM * BK / 1024], rb[BN * BK / 1024];
     const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N);  // workgroup-uniform
@@ -333,12 +315,10 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
     };
     GldsStager<AK, BM> stA;
     GldsStager<BKM, BN> stB;
-    constexpr int NDMA = GLDS ? GldsStager<AK, BM>::NI + GldsStager<BKM, BN>::NI : 0;   // LDS-DMA instructions per wave per K tile
     if (GLDS) {
         stA.init(A, p.lda, m0, p.M, kbeg, wave, lane);
         stB.init(B, p.ldb, n0, p.N, kbeg, wave, lane);
         if (nk > 0) { stA.issue(smem, wave); stB.issue(smem + SA, wave); }
-        if (STAGES == 3 && nk > 1) { stA.issue(smem + (SA + SB), wave); stB.issue(smem + (SA + SB) + SA, wave); }
     } else if (nk > 0) {
         fetch(kbeg);
         store_tile<AK, BM>(smem, ra);
@@ -346,11 +326,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
     }
     // An LDS-DMA is ordered for a ds_read only by the issuing wave's vmcnt wait followed by a barrier: state the wait explicitly
     // instead of relying on the fence hipcc attaches to __syncthreads().
-    // three stages: tile 1 may stay in flight (LDS-DMAs retire in issue order: all but the NDMA youngest = tile 0 has landed)
-    if (GLDS) {
-        if (STAGES == 3 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // Main loop, software-pipelined at two levels so a wave's MFMA stream never waits on LDS latency:
@@ -386,14 +362,6 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #pragma unroll
             for (int a = 0; a < WTM; ++a) csum[a] += (fa[slot][a][0] + fa[slot][a][1]) + (fa[slot][a][2] + fa[slot][a][3]);
         }
-        if (DUAL) {
-#pragma unroll
-            for (int s = 0; s < 4; s += 2) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0][s], fb[slot][0][s], acc[0][0], 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0][s + 1], fb[slot][0][s + 1], acc2, 0, 0, 0);
-            }
-            return;
-        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -404,63 +372,14 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
     };
     int cur = 0;
     if (nk > 0) read_chunk(smem, smem + SA, 0, 0);
-    if constexpr (SPREAD) {
-        constexpr int NA = GldsStager<AK, BM>::NI, NB = GldsStager<BKM, BN>::NI, NP = NA + NB;
-        auto body = [&](auto issue_tag) {
-            constexpr bool ISSUE = decltype(issue_tag)::value;
-            const float* sa = smem + cur * (SA + SB);
-            const float* sb = sa + SA;
-            float* da = smem + (cur ^ 1) * (SA + SB);
-            static_assert(NC == 4, "the spread schedule is written for four k-chunks per tile");
-            auto chunk = [&](auto c_tag) {
-                constexpr int c = decltype(c_tag)::value;
-                read_chunk(sa, sb, c + 1, (c + 1) & 1);
-                // pieces c, c + 3, c + 6 of tile kt+1 ride in this chunk, right behind its first MFMA
-                constexpr int per = (NP - c + 2) / 3;                  // how many of the NP pieces have index = c (mod 3)
-                if constexpr (ISSUE) {
-#pragma unroll
-                    for (int q = 0; q < per; ++q) {
-                        const int j = c + 3 * q;
-                        if (j < NA) stA.issue_piece(da, wave, j); else stB.issue_piece(da + SA, wave, j - NA);
-                    }
-                }
-                mfma_chunk(c & 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if constexpr (ISSUE && per > 0) __builtin_amdgcn_sched_group_barrier(0x020, per, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * WTM * WTN - 1, 0);
-            };
-            chunk(std::integral_constant<int, 0>{});
-            chunk(std::integral_constant<int, 1>{});
-            chunk(std::integral_constant<int, 2>{});
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (ISSUE) read_chunk(da, da + SA, 0, 0);
-            mfma_chunk((NC - 1) & 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * WTM * WTN, 0);
-            cur ^= 1;
-        };
-        for (int kt = 0; kt + 1 < nk; ++kt) body(std::true_type{});
-        if (nk > 0) body(std::false_type{});
-    } else
     for (int kt = 0; kt < nk; ++kt) {
         const float* sa = smem + cur * (SA + SB);
         const float* sb = sa + SA;
         const bool more = kt + 1 < nk;
-        const int nxt = STAGES == 3 ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
-        float* da = smem + nxt * (SA + SB);
-        const bool more2 = STAGES == 3 && kt + 2 < nk;
-        if (GLDS && STAGES == 3) {
-            // tile kt+2 goes into the stage that held tile kt-1: its last fragment reads were waited for before the previous barrier.
-            // The load then has TWO K tiles of MFMAs to land under (the 64-row tiles have only 16 MFMAs per wave between barriers).
-            if (more2) {
-                float* d2 = smem + (nxt == 2 ? 0 : nxt + 1) * (SA + SB);
-                stA.issue(d2, wave); stB.issue(d2 + SA, wave);
-            }
-        } else if (GLDS) {
+        float* da = smem + (cur ^ 1) * (SA + SB);
+        if (GLDS) {
             // the other buffer is free: its last fragment reads were waited for before the previous barrier
-            if (more && DBG != 1) { stA.issue(da, wave); stB.issue(da + SA, wave); }
+            if (more) { stA.issue(da, wave); stB.issue(da + SA, wave); }
         } else if (more) {
             fetch(kbeg + (int64_t)(kt + 1) * BK);
         }
@@ -477,22 +396,15 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
             store_tile<AK, BM>(da, ra);
             store_tile<BKM, BN>(da + SA, rb);
         }
-        if (GLDS) {   // this wave's part of tile kt+1 has landed (see the prologue); with three stages tile kt+2 stays in flight
-            if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (DBG != 2) __syncthreads();
+        if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of tile kt+1 has landed (see the prologue)
+        __syncthreads();
         if (more) read_chunk(da, da + SA, 0, 0);
         mfma_chunk((NC - 1) & 1);
         __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * WTM * WTN, 0);
-        cur = nxt;
+        cur ^= 1;
     }
 
-    if (DUAL) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
-    }
     if (GROUPED && do_colsum) {   // lane halves hold the two k sub-ranges of every chunk: fold them, then lanes h == 0 own row i
 #pragma unroll
         for (int a = 0; a < WTM; ++a) {
@@ -625,11 +537,11 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #ifndef DYN_GEMM_WAVES_PER_EU
 #define DYN_GEMM_WAVES_PER_EU 2
 #endif
-template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, int STAGES = 2, bool DUAL = false, int DBG = 0, bool SPREAD = false>
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DYN_GEMM_WAVES_PER_EU, 8))) void gemm_f32_kernel(const KParams p) {
     constexpr int SA = GLDS ? BM * BK : BM * LDK, SB = GLDS ? BN * BK : BN * LDK;
-    __shared__ __attribute__((aligned(16))) float smem[STAGES * (SA + SB)];
-    gemm_tile<TA, TB, BM, BN, VEC, GLDS, false, STAGES, DUAL, DBG, SPREAD>(p, (int64_t)blockIdx.x, smem);
+    __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
+    gemm_tile<TA, TB, BM, BN, VEC, GLDS, false>(p, (int64_t)blockIdx.x, smem);
 }
 
 // Grouped launch: ONE grid over the tiles of up to kMaxGroups independent GEMMs that share (TA, TB) and the tile shape (the
@@ -781,18 +693,6 @@ Plan make_plan(const dyn_gemm_desc* d) {
         return best;
     }
     const int64_t batch = d->nb1 * d->nb2;
-    // Experiment switch (DYN_GEMM_BIGTILE=1, measurements only): the largest tile that fits the output, no tail slicing, no split-K
-    // unless the output is tiny — the plan for a GPU shared by MANY recording chains, where a launch need not fill the chip by
-    // itself because the workgroups of the other chains' GEMMs occupy the remaining slots.
-    static const bool big = [] { const char* e = getenv("DYN_GEMM_BIGTILE"); return e && atoi(e) != 0; }();
-    if (big && d->split_k == 0) {
-        const int bm = d->M >= 128 ? 128 : 64, bn = d->N >= 128 ? 128 : 64;
-        const int64_t tiles = dyn::cdiv(d->M, bm) * dyn::cdiv(d->N, bn) * batch;
-        int split = 1;
-        if (tiles < 64 && d->K >= 4096) split = (int)(tiles < 8 ? 12 : 4);     // the deep-K subsampling weight gradients
-        eval_config(d, bm, bn, split, 1, &best, &cost);
-        return best;
-    }
     if (d->split_k == 0) {
         for (int i = 0; i < kNumTuned; ++i) {
             const Tuned& t = kTuned[i];
@@ -828,27 +728,6 @@ void launch_vec(const KParams& kp, bool vec, dim3 grid, hipStream_t st) {
     static const bool allow_glds = [] { const char* e = getenv("DYN_GEMM_GLDS"); return !e || atoi(e) != 0; }();
     const bool glds = allow_glds && vec && kp.K % BK == 0 && kp.K > 0 && (!TA || kp.M % 4 == 0) && (TB || kp.N % 4 == 0) &&
                       (!TA || kp.M >= 4) && (TB || kp.N >= 4);
-    // Experiment switch (DYN_GEMM_STAGES3=1: 64x64 tiles, =2: also 64x128 / 128x64): a third LDS stage for the small tiles, whose waves
-    // spend 0.14 - 0.20 of their cycles parked at the once-per-K-tile load wait (profiles/r03_gemm_sq_counters_by_tile.txt)
-    static const int stages3 = [] { const char* e = getenv("DYN_GEMM_STAGES3"); return e ? atoi(e) : 0; }();
-    constexpr bool small = BM * BN <= 64 * 64, mid = BM * BN == 64 * 128;
-    static const int spread = [] { const char* e = getenv("DYN_GEMM_SPREAD"); return e ? atoi(e) : 0; }();     // 1: 64-row tiles, 2: every tile
-    if (glds && (spread >= 2 || (spread == 1 && BM * BN <= 64 * 128))) {
-        hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true, 2, false, 0, true>), grid, dim3(NTHREADS), 0, st, kp);
-        return;
-    }
-    static const int dbg = [] { const char* e = getenv("DYN_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
-    if constexpr (small && !TA && TB) {      // diagnostic builds: NT 64x64 only
-        if (glds && dbg == 1) { hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true, 2, false, 1>), grid, dim3(NTHREADS), 0, st, kp); return; }
-        if (glds && dbg == 2) { hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true, 2, false, 2>), grid, dim3(NTHREADS), 0, st, kp); return; }
-    }
-    static const bool dualacc = [] { const char* e = getenv("DYN_GEMM_DEBUG_UNUSED"); (void)e; const char* f = getenv("DYN_GEMM_DUALACC"); return f && atoi(f) != 0; }();
-    if (glds && small && dualacc) {
-        if constexpr (small) { hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true, 2, true>), grid, dim3(NTHREADS), 0, st, kp); return; }
-    }
-    if (glds && ((small && stages3 >= 1) || (mid && stages3 >= 2))) {
-        if constexpr (small || mid) { hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true, 3>), grid, dim3(NTHREADS), 0, st, kp); return; }
-    }
     if (glds) hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true>), grid, dim3(NTHREADS), 0, st, kp);
     else if (vec) hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, false>), grid, dim3(NTHREADS), 0, st, kp);
     else hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, false, false>), grid, dim3(NTHREADS), 0, st, kp);

@@ -1,4 +1,5 @@
-"""Diagnostic: NT 64x64-tile GEMM (N = 4096, K = 3072, 4 rounds) under DYN_GEMM_DEBUG = 0 / 1 / 2 (set in the environment of the
+"""(Needs the diagnostic kernel builds of commit 8bcdd1b: the DYN_GEMM_DEBUG switch was removed from the product source after the measurement.)
+Diagnostic: NT 64x64-tile GEMM (N = 4096, K = 3072, 4 rounds) under DYN_GEMM_DEBUG = 0 / 1 / 2 (set in the environment of the
 process: the switch is read once).  1 = no direct-to-LDS loads in the K loop, 2 = no workgroup barrier in the K loop (results are garbage)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
