@@ -459,6 +459,9 @@ def dynamic_eval_ctc_loss(args, model, spec, seq_len, overlap, tokenizer, use_tq
             next(gen)
     except StopIteration as stop:
         return stop.value
+    finally:
+        if _is_native(model):
+            model.grad_samples = None      # also when the loop raised: a stale value would make a later full-batch backward fail
 
 
 def _new_chain_stream(device, k):
@@ -520,6 +523,17 @@ def dynamic_eval_many(args, models, specs, seq_len, overlap, tokenizer, **kw):
     pending = list(enumerate(specs))
     results = [None] * len(specs)
     free, active = list(range(len(models)))[::-1], []
+    try:
+        _run_chains(args, models, streams, pending, results, free, active, seq_len, overlap, tokenizer, kw)
+    finally:
+        _reset_grad_samples(models)
+    for st in streams:
+        main.wait_stream(st)
+    return results
+
+
+def _run_chains(args, models, streams, pending, results, free, active, seq_len, overlap, tokenizer, kw):
+    """Round-robin over the chains' generators (see dynamic_eval_many)."""
     while pending or active:
         while pending and free:
             ci = free.pop()
@@ -534,9 +548,12 @@ def dynamic_eval_many(args, models, specs, seq_len, overlap, tokenizer, **kw):
                     results[idx] = stop.value
                     active.remove(item)
                     free.append(ci)
-    for st in streams:
-        main.wait_stream(st)
-    return results
+
+
+def _reset_grad_samples(models):
+    for m in models:
+        if _is_native(m):
+            m.grad_samples = None
 
 
 dynamic_eval = dynamic_eval_ctc_loss
