@@ -208,6 +208,9 @@ def test_bench_contract(cuda):
     # representative labels in the timed region, the degenerate (collapsing) labels and the boundary-faithful rate beside it
     assert d["config"]["label_tokens_per_window"] == 400 and d["value_degenerate_labels"] > 0 and d["value_boundary"] > 0 and d["value_online"] > d["value"]
     assert d["hyp_tokens_total"] >= 0 and "wer_counters" not in d
+    # the path's other loops get a driver-visible number too (untimed for `value`)
+    ow = d["other_workloads"]
+    assert set(ow) == {"awmc", "wav2vec2_su", "enc_dec_teacher_ce"} and all(v.get("value", 0) > 0 and v["unit"] == "audio-s/s" for v in ow.values()), ow
 
 
 def test_run_cross_speaker_gender(cuda, tmp_path, capsys):
