@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — dynamic-eval throughput on MI355X (metric and workload of BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a torchrun environment: starts its N ranks itself, self_launch())
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One STEP = one pass of the hot path over one synthetic recording of the Earnings-22 long-form shape
@@ -13,8 +13,9 @@ timed region starts.  Weak scaling: every rank adapts on its own recordings (the
 fresh optimiser per call); the only collective is the WER-counter all-reduce after the timed region.
 
 Prints ONE JSON line on rank 0 with `roofline` (fp32-MFMA GEMM family, measured live with HIP events on the launch
-stream) and, at N=1, `cpu_baseline` (the CPU oracle restatement timed on the host cores on a bounded sample), `parity`
-(the cpu_baseline windows through the HIP path with the same weights and masks, compared with the oracle's outputs),
+stream) and, at N=1, `cpu_baseline` (the CPU oracle restatement timed on the host cores on a bounded sample: ONE weight-carrying
+recording of 8 windows + tail), `parity` (that recording through the HIP path with the same weights and masks, offline and online,
+compared with the oracle's outputs), `other_workloads` (AWMC, wav2vec2 dynamic_eval_su, enc-dec teacher_ce: audio-s/s of the path's other loops),
 `value_degenerate_labels` (the model's own collapsing pseudo-labels instead of --label_tokens seeded ids per window),
 `value_boundary` (recordings start in host memory, log-probs come back as numpy: the reference's call contract) and `value_online`
 (`online=True`: the adapt loop's own clean-copy posteriors are stitched, no final pass — the mode of the reference's published timing)."""
