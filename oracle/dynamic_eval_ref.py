@@ -110,7 +110,7 @@ def dynamic_eval_ref(model, spec, seq_len, overlap, tokenizer, optimizer_cls, lr
     `timings` (benchmarks only): a dict that receives 'adapt' / 'final' = seconds per window of the two loops.
     `also_online` (tests only, offline mode): the adaptation loop is the same in both modes, so one run can also hand back what
     `online=True` would have stitched (the clean copy's posteriors of every adapt step, lib.py:583-589) -> (offline, online[, params]).
-    A float64 model / spectrogram runs the whole loop in float64 (the noise-floor reference of scripts/drift_check.py)."""
+    A float64 model / spectrogram runs the whole loop in float64 (the noise-floor reference of tests/drift_check.py)."""
     import time
     spec_n = spec.shape[-1]
     original_model_params = [p.clone().detach().cpu() for p in model.parameters()]

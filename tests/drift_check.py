@@ -13,7 +13,7 @@ after ONE step at lr 9e-5).
 Per 256-row band of the stitched output (one band = the 2048-frame stride): the online curve shows the drift after k adapt
 steps (band b >= 8 is covered by windows b-7 ... only), the offline curve the final pass with the fully adapted weights.
 
-  python scripts/drift_check.py [--windows 8] [--fp64 1] [--grad_diag 1] [--out profiles/r03_drift.json]
+  python tests/drift_check.py [--windows 8] [--fp64 1] [--grad_diag 1] [--out profiles/r03_drift.json]
 """
 import argparse
 import json
@@ -21,7 +21,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repository root
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402

@@ -261,7 +261,7 @@ def test_ctc_loss_and_grad(cuda, T, C, S, reduction):
     rel = abs(loss.item() - loss_ref.item()) / max(1.0, abs(loss_ref.item()))
     assert rel < 2e-6 * max(1, T // 64), (loss.item(), loss_ref.item())   # fp32 lattice, T serial log-sum-exps
     # |grad| <= scale per element; the fp32 lattice's log-domain error grows with the T serial log-sum-exps and with |alpha| ~ T * |lp|
-    # (ulp(20000) = 2e-3 at T = 4200, C = 129: torch's own fp32 lattice is as far from float64 as this one, scripts/drift_check.py)
+    # (ulp(20000) = 2e-3 at T = 4200, C = 129: torch's own fp32 lattice is as far from float64 as this one, tests/drift_check.py)
     _close(grad, lpr.grad, scale * max(1.3e-3, 4e-6 * T), "ctc grad")
 
 
