@@ -67,6 +67,7 @@ struct KParams {
     float colsum_beta;
     int64_t first_item;  // first work item of this group in the grouped launch
     int wide;            // 1: C (and C_in, bias) allow 16-byte accesses -> interior tiles go through the LDS-transposed epilogue
+    int nt;              // 1: the epilogue stores C with the non-temporal hint (write-through as the kernel runs, see the wide epilogue)
 };
 
 // alpha * acc + beta * c_in + bias in ONE pinned operation order (explicit mul / fma / add: no contraction differences between the
@@ -515,7 +516,13 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
                 o.x = epi_value(p.alpha, v.x, 0.f, nullptr, bv.x); o.y = epi_value(p.alpha, v.y, 0.f, nullptr, bv.y);
                 o.z = epi_value(p.alpha, v.z, 0.f, nullptr, bv.z); o.w = epi_value(p.alpha, v.w, 0.f, nullptr, bv.w);
             }
-            *reinterpret_cast<float4*>(cp) = o;
+            // Non-temporal stores: with plain stores the output stays dirty in the XCDs' L2s (8 x 4 MB, not coherent with each other) until
+            // the END of the kernel, and the launch then pays the write-back of up to 32 MB with nothing left to hide it under: 36.6 us
+            // per 128x128 launch at K = 768 against 4.3 us with `nt` stores, which leave as the kernel runs (+3 us per round of tiles;
+            // diagnostic builds with no / L2-resident / nt / sc1 stores, profiles/r03_probe_gemm_store_flavours.log).
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            if (p.nt) __builtin_nontemporal_store(v4f{o.x, o.y, o.z, o.w}, reinterpret_cast<v4f*>(cp));
+            else *reinterpret_cast<float4*>(cp) = o;
         }
     } else if (m0 + BM <= p.M && n0 + BN <= p.N) {  // interior tile: unguarded stores
         float* C = p.C + z1 * p.sc1 + z2 * p.sc2;
@@ -843,6 +850,8 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
     {   // 16-byte epilogue: every address it touches must be 16-byte aligned (tile offsets are multiples of 32 floats)
         static const bool allow_wide = [] { const char* e = getenv("DYN_GEMM_WIDE_EPILOGUE"); return !e || atoi(e) != 0; }();
         auto a16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+        static const bool allow_nt = [] { const char* e = getenv("DYN_GEMM_NT_STORES"); return !e || atoi(e) != 0; }();
+        kp.nt = allow_nt ? 1 : 0;
         kp.wide = allow_wide && a16(d->C) && d->ldc % 4 == 0 && d->sc1 % 4 == 0 && d->sc2 % 4 == 0 && (!d->C_in || a16(d->C_in)) &&
                   (!d->bias || a16(d->bias)) ? 1 : 0;
     }
@@ -923,6 +932,8 @@ extern "C" int dyn_gemm_f32_grouped(const dyn_gemm_desc* descs, int32_t n, void*
         kp.epi = 0; kp.aux = nullptr; kp.counters = nullptr;
         kp.colsum = d->a_colsum; kp.colsum_beta = d->a_colsum_beta;
         kp.wide = (al16(d->C) && d->ldc % 4 == 0 && (!d->C_in || al16(d->C_in))) ? 1 : 0;
+        static const bool allow_nt_g = [] { const char* e = getenv("DYN_GEMM_NT_STORES"); return !e || atoi(e) != 0; }();
+        kp.nt = allow_nt_g ? 1 : 0;
         kp.first_item = total;
         total += kp.tiles_per_batch;
     }

@@ -1,4 +1,4 @@
-"""(Diagnostic build only: epilogue code 77 = return before the stores.)  128x128 NT launches with and without the epilogue: is the ~30 us per
+"""(Diagnostic build only: epilogue codes 77 = return before the stores, 78 = every tile stores into the first tile (L2 hits), 79 = nt stores, 80 = sc1 write-through stores.)  128x128 NT launches with and without the epilogue: is the ~30 us per
 launch at K = 768 the exposed last epilogue?"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,7 @@ def timeit(f, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 N, K = 4096, 768
-for epi in (0, 77):
+for epi in (0, 77, 78, 79, 80):
     pts = []
     for rounds in (1, 2, 3, 4, 8):
         M = int(rounds * 512) // (N // 128) * 128
