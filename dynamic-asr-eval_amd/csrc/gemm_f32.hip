@@ -66,8 +66,6 @@ struct KParams {
     float* colsum;       // [M]: colsum[m] = colsum_beta * colsum[m] + sum_k A(m, k)   (bias gradient of a weight-gradient GEMM)
     float colsum_beta;
     int64_t first_item;  // first work item of this group in the grouped launch
-    int wide;            // 1: C (and C_in, bias) allow 16-byte accesses -> interior tiles go through the LDS-transposed epilogue
-    int nt;              // 1: the epilogue stores C with the non-temporal hint (write-through as the kernel runs, see the wide epilogue)
 };
 
 // alpha * acc + beta * c_in + bias in ONE pinned operation order (explicit mul / fma / add: no contraction differences between the
@@ -482,49 +480,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
             }
         if (threadIdx.x == 0) p.counters[pt] = 0;     // ready for the next launch on this stream
     }
-    if (p.wide && p.epi == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {
-        // Interior tile, 16-byte epilogue.  In the MFMA C layout a lane holds 4 consecutive ROWS of one column, so the direct store is
-        // 64 (128x128) dword stores per lane — and the last round of a launch has nothing to hide them under: a diagnostic build
-        // without the epilogue takes ~36 us less PER LAUNCH at K = 768 (scripts/probe_gemm_noepilogue.py).  Here each wave turns its
-        // (BM/2) x (BN/2) sub-tile through its own quarter of the (now idle) staging LDS — no workgroup barrier: a wave only reads what
-        // it wrote, LDS operations of one wave execute in order — and stores rows as float4: 16 stores per lane instead of 64, each
-        // wave-instruction covering whole 256-byte (128-byte for BN = 64) row segments.  Same arithmetic per element: bit-identical.
-        constexpr int RW = BM / 2, CW = BN / 2, C4 = CW / 4, ROWS_PER = 64 / C4, NQ = RW / ROWS_PER;
-        float* my = smem + wave * (RW * CW);
-#pragma unroll
-        for (int a = 0; a < WTM; ++a)
-#pragma unroll
-            for (int b = 0; b < WTN; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) my[(a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CW + b * 32 + i] = acc[a][b][e];
-        float* C = p.C + z1 * p.sc1 + z2 * p.sc2;
-        const int c4 = lane % C4, r_in = lane / C4;
-        const int64_t col = n0 + wn * CW + 4 * c4;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + col);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int r = q * ROWS_PER + r_in;
-            const float4 v = *reinterpret_cast<const float4*>(&my[r * CW + 4 * c4]);
-            float* cp = C + (m0 + wm * RW + r) * p.ldc + col;
-            float4 o;
-            if (p.beta != 0.f) {
-                const float4 ci = *reinterpret_cast<const float4*>(cp + p.cin_delta);
-                o.x = epi_value(p.alpha, v.x, p.beta, &ci.x, bv.x); o.y = epi_value(p.alpha, v.y, p.beta, &ci.y, bv.y);
-                o.z = epi_value(p.alpha, v.z, p.beta, &ci.z, bv.z); o.w = epi_value(p.alpha, v.w, p.beta, &ci.w, bv.w);
-            } else {
-                o.x = epi_value(p.alpha, v.x, 0.f, nullptr, bv.x); o.y = epi_value(p.alpha, v.y, 0.f, nullptr, bv.y);
-                o.z = epi_value(p.alpha, v.z, 0.f, nullptr, bv.z); o.w = epi_value(p.alpha, v.w, 0.f, nullptr, bv.w);
-            }
-            // Non-temporal stores: with plain stores the output stays dirty in the XCDs' L2s (8 x 4 MB, not coherent with each other) until
-            // the END of the kernel, and the launch then pays the write-back of up to 32 MB with nothing left to hide it under: 36.6 us
-            // per 128x128 launch at K = 768 against 4.3 us with `nt` stores, which leave as the kernel runs (+3 us per round of tiles;
-            // diagnostic builds with no / L2-resident / nt / sc1 stores, profiles/r03_probe_gemm_store_flavours.log).
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            if (p.nt) __builtin_nontemporal_store(v4f{o.x, o.y, o.z, o.w}, reinterpret_cast<v4f*>(cp));
-            else *reinterpret_cast<float4*>(cp) = o;
-        }
-    } else if (m0 + BM <= p.M && n0 + BN <= p.N) {  // interior tile: unguarded stores
+    if (m0 + BM <= p.M && n0 + BN <= p.N) {  // interior tile: unguarded stores
         float* C = p.C + z1 * p.sc1 + z2 * p.sc2;
 #pragma unroll
         for (int a = 0; a < WTM; ++a)
@@ -847,14 +803,6 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
     // every other kernel that shares it.  Kept because it is bit-identical and needs no second launch when a GEMM runs alone.
     kp.counters = (d->counters && n_ptiles > 0 && n_ptiles <= d->n_counters) ? d->counters : nullptr;
     kp.colsum = nullptr; kp.colsum_beta = 0.f; kp.first_item = 0;
-    {   // 16-byte epilogue: every address it touches must be 16-byte aligned (tile offsets are multiples of 32 floats)
-        static const bool allow_wide = [] { const char* e = getenv("DYN_GEMM_WIDE_EPILOGUE"); return !e || atoi(e) != 0; }();
-        auto a16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
-        static const bool allow_nt = [] { const char* e = getenv("DYN_GEMM_NT_STORES"); return !e || atoi(e) != 0; }();
-        kp.nt = allow_nt ? 1 : 0;
-        kp.wide = allow_wide && a16(d->C) && d->ldc % 4 == 0 && d->sc1 % 4 == 0 && d->sc2 % 4 == 0 && (!d->C_in || a16(d->C_in)) &&
-                  (!d->bias || a16(d->bias)) ? 1 : 0;
-    }
     const int64_t nblocks = pl.full_items + pl.tail_items * pl.tail_f;
     DYN_REQUIRE(nblocks < (1ll << 31) && tiles_m * tiles_n < (1ll << 31), DYN_E_ARG, "dyn_gemm_f32: grid too large (%lld workgroups)",
                 (long long)nblocks);
@@ -931,9 +879,6 @@ extern "C" int dyn_gemm_f32_grouped(const dyn_gemm_desc* descs, int32_t n, void*
         kp.full_items = kp.tiles_per_batch; kp.tail_f = 1; kp.tail_ws = nullptr;
         kp.epi = 0; kp.aux = nullptr; kp.counters = nullptr;
         kp.colsum = d->a_colsum; kp.colsum_beta = d->a_colsum_beta;
-        kp.wide = (al16(d->C) && d->ldc % 4 == 0 && (!d->C_in || al16(d->C_in))) ? 1 : 0;
-        static const bool allow_nt_g = [] { const char* e = getenv("DYN_GEMM_NT_STORES"); return !e || atoi(e) != 0; }();
-        kp.nt = allow_nt_g ? 1 : 0;
         kp.first_item = total;
         total += kp.tiles_per_batch;
     }
