@@ -6,6 +6,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dynamic_asr_eval_amd import ops
 dev = torch.device("cuda:0")
+
+
+def warm(seconds=6.0):
+    import time
+    a = torch.randn(8192, 3072, device=dev); b = torch.randn(4096, 3072, device=dev); c = torch.empty(8192, 4096, device=dev)
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        for _ in range(20):
+            ops.gemm(a, b, c, trans_b=True, M=8192, N=4096, K=3072, lda=3072, ldb=3072, ldc=4096, force=(128, 128, 1))
+        torch.cuda.synchronize()
+
+
+warm()
 for K in (768, 3072):
     M, N = 4096, 4096
     a = torch.randn(M, K, device=dev); b = torch.randn(N, K, device=dev); c = torch.empty(M, N, device=dev)
