@@ -248,7 +248,11 @@ def cpu_baseline(a, hip_model, dev):
     return base, parity
 
 
-def other_workloads(a, model, dev):
+class _Skip(Exception):
+    pass
+
+
+def other_workloads(a, model, dev, which=('awmc', 'wav2vec2_su', 'enc_dec_teacher_ce')):
     """Driver-visible throughput of the path's other loops (one recording each, one chain, second of two runs; untimed as far as
     `value` goes).  Same kernels, same C-ABI; shapes: AWMC on a 10-min recording of the benchmark's model and window; wav2vec2-base
     (Wav2Vec2Config() defaults, seeded) `dynamic_eval_su` over a 5-min TEDLIUM-shape talk cut by the reference's fetch_utterances
@@ -272,15 +276,21 @@ def other_workloads(a, model, dev):
         return min(ts)
 
     try:
+        if 'awmc' not in which:
+            raise _Skip
         secs = 600.0
         spec = synthetic_spec(int(secs * 100), seed=4242).to(dev)
         args = make_args(a)
         tok = SyntheticTokenizer(a.vocab)
         dt = best_of_two(lambda: lib.AWMC(args, model, spec, a.seq_len, a.overlap, tok, use_tqdm=False, return_device=True))
         out["awmc"] = {"value": round(secs / dt, 1), "unit": "audio-s/s", "sample": f"{secs:.0f} s recording, seq_len {a.seq_len} / overlap {a.overlap}, 1 chain"}
+    except _Skip:
+        pass
     except Exception as e:                              # a side measurement must never take the headline down with it
         out["awmc"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     try:
+        if 'wav2vec2_su' not in which:
+            raise _Skip
         from dynamic_asr_eval_amd import run_wav2vec2 as RW, wav2vec2_lib as W
         from dynamic_asr_eval_amd.wav2vec2_model import Wav2Vec2ForCTC
         wm = Wav2Vec2ForCTC(None, device=dev)
@@ -293,9 +303,13 @@ def other_workloads(a, model, dev):
                                                    lr_args={'lr': 1e-6}))
         out["wav2vec2_su"] = {"value": round(audio_s / dt, 1), "unit": "audio-s/s", "sample": f"{len(utts)} utterances, {audio_s:.0f} s of 16 kHz audio, wav2vec2-base shape"}
         del wm
+    except _Skip:
+        pass
     except Exception as e:
         out["wav2vec2_su"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     try:
+        if 'enc_dec_teacher_ce' not in which:
+            raise _Skip
         from dynamic_asr_eval_amd.enc_dec import EncDecSCConformerXL, enc_dec_dynamic_eval
         from dynamic_asr_eval_amd.synthetic_weights import init_synthetic
         em = EncDecSCConformerXL({}, vocab_size=a.vocab, device=dev)
@@ -307,6 +321,8 @@ def other_workloads(a, model, dev):
         dt = best_of_two(lambda: enc_dec_dynamic_eval(eargs, em, spec, 2048, 0, SyntheticTokenizer(a.vocab), use_tqdm=False))
         out["enc_dec_teacher_ce"] = {"value": round(secs / dt, 1), "unit": "audio-s/s", "sample": f"{secs:.0f} s recording, 2048-frame windows, KV-cached greedy teacher + final decode"}
         del em
+    except _Skip:
+        pass
     except Exception as e:
         out["enc_dec_teacher_ce"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return out

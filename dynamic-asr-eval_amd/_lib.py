@@ -37,6 +37,22 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class DecoderDesc(ctypes.Structure):
+    """Mirror of dyn_decoder_desc (include/dyneval.h)."""
+    _fields_ = [
+        ("d_model", ctypes.c_int32), ("heads", ctypes.c_int32), ("d_ff", ctypes.c_int32), ("vocab", ctypes.c_int32),
+        ("layers", ctypes.c_int32), ("n_enc", ctypes.c_int32), ("max_positions", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+        ("eps", ctypes.c_float), ("reserved2_", ctypes.c_float),
+        ("embed", ctypes.c_void_p), ("pos_table", ctypes.c_void_p), ("norm_out_w", ctypes.c_void_p), ("norm_out_b", ctypes.c_void_p),
+        ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p),
+        ("layer_ptrs", ctypes.POINTER(ctypes.c_void_p)),
+        ("tokens", ctypes.c_void_p), ("logits", ctypes.c_void_p), ("scratch", ctypes.c_void_p), ("scratch_floats", ctypes.c_int64),
+    ]
+
+
+DEC_PTRS_PER_LAYER = 18
+
+
 def load():
     """Load the shared library once; raise loudly when it has not been built."""
     global _lib
@@ -85,6 +101,7 @@ def prototypes():
     text = open(hdr).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"typedef struct \{.*?\} \w+;", "", text, flags=re.S)
+    text = re.sub(r"^[ \t]*#.*$", "", text, flags=re.M)
     protos = {}
     for ret, name, args in re.findall(r"([\w\s\*]+?)\b(dyn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
         ret = ret.strip()
@@ -95,7 +112,8 @@ def prototypes():
         argtypes = []
         for a in [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]:
             if "*" in a:
-                argtypes.append(ctypes.POINTER(GemmDesc) if "dyn_gemm_desc" in a else ctypes.c_void_p)
+                argtypes.append(ctypes.POINTER(GemmDesc) if "dyn_gemm_desc" in a else
+                                ctypes.POINTER(DecoderDesc) if "dyn_decoder_desc" in a else ctypes.c_void_p)
             else:
                 argtypes.append(_CTYPES[a.replace("const ", "").split()[0]])
         protos[name] = (restype, argtypes)

@@ -57,6 +57,19 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return t;
 }
 
+// Counter-based randomness (include/dyneval.h, dyn_dropout): a draw is a pure function of (seed, stream, index).
+__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t stream, uint64_t index) {
+    uint64_t z = seed ^ ((stream + 1) * 0x9E3779B97F4A7C15ull) ^ ((index + 1) * 0xC2B2AE3D27D4EB4Full);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// the Gumbel-max key of class c: x * inv_t - log(-log(u)), u = odd / 2^24 in (0, 1)
+__device__ __forceinline__ float gumbel_key(float x, float inv_t, uint64_t seed, uint64_t stream, uint64_t c) {
+    const float u = (float)(2 * (mix64(seed, stream, c) >> 41) + 1) * 5.9604644775390625e-8f;
+    return x * inv_t - logf(-logf(u));
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

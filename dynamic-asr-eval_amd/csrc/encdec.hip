@@ -59,13 +59,8 @@ __global__ __launch_bounds__(256) void nll_grad_kernel(const float* __restrict__
     }
 }
 
-// ---- counter-based randomness: a draw is a pure function of (seed, stream, index); see include/dyneval.h
-__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t stream, uint64_t index) {
-    uint64_t z = seed ^ ((stream + 1) * 0x9E3779B97F4A7C15ull) ^ ((index + 1) * 0xC2B2AE3D27D4EB4Full);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
+// ---- counter-based randomness: a draw is a pure function of (seed, stream, index); see include/dyneval.h (dyn::mix64 in common.h)
+using dyn::mix64;
 
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p, float scale,
                                                       uint64_t seed, uint64_t stream) {
@@ -84,8 +79,7 @@ __global__ __launch_bounds__(256) void gumbel_argmax_rows_kernel(const float* __
         float bv = -INFINITY;
         int bi = 0x7fffffff;
         for (int c = lane; c < C; c += 64) {
-            const float u = (float)(2 * (mix64(seed, step0 + (uint64_t)row, (uint64_t)c) >> 41) + 1) * 5.9604644775390625e-8f;  // odd / 2^24 in (0, 1)
-            const float v = xr[c] * inv_t - logf(-logf(u));
+            const float v = dyn::gumbel_key(xr[c], inv_t, seed, step0 + (uint64_t)row, (uint64_t)c);
             if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
         }
 #pragma unroll

@@ -17,14 +17,16 @@ dropout_post_ff / dropout_attn` (:1511-1522,1636-1637,1703-1707).  Randomness is
 a draw is a pure function of (seed, stream, index)), so it is reproducible and the oracle restates it exactly.  The RL modes
 (`grpo`, `maxrl`: sampled rollouts, reward models) are out of scope and raise.  Decoder parameters live in the encoder's flat
 buffers (SCConformerXL(extra_spec=...)), so snapshot / restore / MADGRAD step are the same single operations as on the CTC path."""
+import ctypes
 import math
+import os
 import random
 from types import SimpleNamespace
 
 import torch
 
 from . import ops
-from ._lib import check, load
+from ._lib import DEC_PTRS_PER_LAYER, DecoderDesc, check, load
 from .augment import SpecAugment
 from .decoding import GreedyCTCDecoder
 from .enc_dec_teacher_filters import should_skip_faulty_teacher_prediction
@@ -127,6 +129,10 @@ class EncDecSCConformerXL(SCConformerXL):
         self.pos_enc = _NoParams()
         self.use_graphs = False
         self._dctx = None
+        # generate(): the lean one-token kernels of dyn_decoder_steps (default) or, with DYN_FUSED_DECODE=0, the tile kernels at M = 1
+        hd = self.dec["dec_d_model"] // self.dec["dec_heads"]
+        self.fused_decode = (os.environ.get("DYN_FUSED_DECODE", "1") != "0" and self.dec["dec_d_model"] * self.dec["dec_ff_mult"] <= 2048
+                             and 4 <= hd <= 256 and hd & (hd - 1) == 0)
         self.random_seed = 0          # seed of the counter-based dropout / sampling draws (args.random_seed in the loop)
         self._draws = 0               # one stream id per random site and call: no draw is ever reused
 
@@ -171,8 +177,14 @@ class EncDecSCConformerXL(SCConformerXL):
                 cache = [torch.empty(limit + 1, 3 * dd, device=self.device, dtype=torch.float32) for _ in range(L)]
                 tok_dev = torch.zeros(limit + 2, dtype=torch.int32, device=self.device)           # tok_dev[0] = bos
                 n_tok, t = None, 0
+                fused = self._decoder_desc(kv, cache, tok_dev, h.shape[0]) if self.fused_decode else None
                 while t < limit and n_tok is None:
-                    for _ in range(min(check_every, limit - t)):
+                    n = min(check_every, limit - t)
+                    if fused is not None:                                                          # one C call, 8 * layers + 2 launches per token
+                        check(load().dyn_decoder_steps(ctypes.byref(fused[0]), t, n, 1 if sample else 0, 1.0 / float(temperature) if sample else 1.0,
+                                                       int(seed) if sample else 0, int(step0) if sample else 0, st), "dyn_decoder_steps")
+                        t += n
+                    for _ in range(0 if fused is not None else n):                                 # the tile-kernel path (DYN_FUSED_DECODE=0)
                         logits = self._decoder_step(tok_dev, t, h, kv, cache)                     # [1, V]
                         nxt = tok_dev[t + 1:]
                         if sample:
@@ -186,6 +198,31 @@ class EncDecSCConformerXL(SCConformerXL):
                         n_tok = got.index(0)
                 toks = tok_dev[1:t + 1].tolist()[:n_tok] if n_tok is not None else tok_dev[1:t + 1].tolist()
         return {"text_sequence": toks}
+
+    def _decoder_desc(self, kv, cache, tok_dev, n_enc):
+        """dyn_decoder_desc of one generate() call (include/dyneval.h): returns (descriptor, objects it points into)."""
+        P, dc = self.P, self.dec
+        dd, L = dc["dec_d_model"], dc["dec_layers"]
+        ff = dd * dc["dec_ff_mult"]
+        names = ("self.norm.weight", "self.norm.bias", "self.qkv.weight", "self.qkv.bias", "self.out.weight", "self.out.bias",
+                 "cross.norm.weight", "cross.norm.bias", "cross.q.weight", "cross.q.bias", "cross.out.weight", "cross.out.bias",
+                 "ff.norm.weight", "ff.norm.bias", "ff.w1.weight", "ff.w2.weight")
+        ptrs = (ctypes.c_void_p * (L * DEC_PTRS_PER_LAYER))()
+        for l in range(L):
+            for i, nm in enumerate(names):
+                ptrs[l * DEC_PTRS_PER_LAYER + i] = P[f"{DEC}layers.{l}.{nm}"].data_ptr()
+            ptrs[l * DEC_PTRS_PER_LAYER + 16] = cache[l].data_ptr()
+            ptrs[l * DEC_PTRS_PER_LAYER + 17] = kv[l].data_ptr()
+        logits = torch.empty(self.vocab, device=self.device, dtype=torch.float32)
+        scratch = torch.empty(3 * dd + ff, device=self.device, dtype=torch.float32)
+        d = DecoderDesc(d_model=dd, heads=dc["dec_heads"], d_ff=ff, vocab=self.vocab, layers=L, n_enc=int(n_enc),
+                        max_positions=dc["dec_max_positions"], eps=float(self.config["norm_eps"]),
+                        embed=P[DEC + "embed.weight"].data_ptr(), pos_table=self.pos_table.data_ptr(),
+                        norm_out_w=P[DEC + "norm_out.weight"].data_ptr(), norm_out_b=P[DEC + "norm_out.bias"].data_ptr(),
+                        head_w=P[DEC + "head.weight"].data_ptr(), head_b=P[DEC + "head.bias"].data_ptr(),
+                        layer_ptrs=ctypes.cast(ptrs, ctypes.POINTER(ctypes.c_void_p)), tokens=tok_dev.data_ptr(), logits=logits.data_ptr(),
+                        scratch=scratch.data_ptr(), scratch_floats=scratch.numel())
+        return d, (ptrs, logits, scratch)
 
     def _next_stream(self):
         """A fresh block of 2^20 stream ids for one random site (dropout mask) or one sampled decode (one id per step)."""

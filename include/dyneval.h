@@ -316,6 +316,40 @@ int dyn_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uin
 int dyn_gumbel_argmax_rows(const float* x, int64_t rows, int64_t C, int64_t ld, float inv_temperature, uint64_t seed, uint64_t step0,
                            int32_t* ids, void* stream);
 
+/* The autoregressive decode of `model.generate` (reference call sites lcasr/lib.py:1128,1579-1582,1620-1625; the model class itself
+ * is un-vendored) one token at a time with cached keys / values: ONE call runs `n_steps` consecutive positions t0 .. t0 + n_steps - 1
+ * as 8 * layers + 2 lean launches per token (a row-times-matrix kernel with the LayerNorm / embedding prologue and the bias / SiLU /
+ * residual epilogue fused, and a one-query attention kernel per head), instead of ~57 launches of the tile kernels at M = 1.
+ * Per position t: x = embed[tokens[t]] + pos_table[t]; per layer: self-attention over cache rows 0 .. t (row t = the packed q | k | v
+ * of this position, written here), cross-attention over the n_enc projected encoder rows, SiLU feed-forward; then
+ * logits = head(norm_out(x)) and tokens[t + 1] = argmax (sample == 0, first maximum wins) or the Gumbel-max draw of
+ * dyn_gumbel_argmax_rows with stream = step0 + t (sample != 0).  Nothing is read back: the caller looks for eos when it likes.
+ * layer_ptrs: HOST array of layers * DYN_DEC_PTRS_PER_LAYER device pointers, per layer in this order:
+ *   self.norm.weight, self.norm.bias, self.qkv.weight [3d, d], self.qkv.bias, self.out.weight [d, d], self.out.bias,
+ *   cross.norm.weight, cross.norm.bias, cross.q.weight [d, d], cross.q.bias, cross.out.weight [d, d], cross.out.bias,
+ *   ff.norm.weight, ff.norm.bias, ff.w1.weight [d_ff, d], ff.w2.weight [d, d_ff],
+ *   cache [>= t0 + n_steps rows, 3d] (read / written), cross_kv [n_enc, 2d] (keys | values of the encoder states).
+ * Limits: d_model % 256 == 0, d_model <= 2048, d_ff % 256 == 0, d_ff <= 2048, head dim a power of two in 4 .. 256,
+ * t0 + n_steps <= max_positions, keys per attention <= 12288. */
+#define DYN_DEC_PTRS_PER_LAYER 18
+typedef struct {
+    int32_t d_model, heads, d_ff, vocab, layers, n_enc, max_positions, reserved_;
+    float eps, reserved2_;
+    const float* embed;        /* [vocab, d] */
+    const float* pos_table;    /* [max_positions, d] */
+    const float* norm_out_w;
+    const float* norm_out_b;
+    const float* head_w;       /* [vocab, d] */
+    const float* head_b;
+    const void* const* layer_ptrs;
+    int32_t* tokens;           /* device, >= t0 + n_steps + 1 entries; tokens[t0] must be valid on entry */
+    float* logits;             /* device [vocab]: the logits of the last position run */
+    float* scratch;            /* device, >= 3 * d_model + d_ff floats */
+    int64_t scratch_floats;
+} dyn_decoder_desc;
+int dyn_decoder_steps(const dyn_decoder_desc* d, int32_t t0, int32_t n_steps, int32_t sample, float inv_temperature, uint64_t seed,
+                      uint64_t step0, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * CTC.  dyn_ctc_greedy replaces GreedyCTCDecoder on a CPU copy of the posteriors (reference lcasr/lib.py:498,
  * 559,565; run_dynamic_eval_full.py:53,100): argmax over classes (first maximum), collapse repeats, drop `blank`.

@@ -152,6 +152,70 @@ def test_generate_with_kv_cache_greedy_and_sampled_matches_oracle(cuda):
     assert short == want[:2]
 
 
+@pytest.mark.parametrize("dec", [dict(dec_d_model=256, dec_layers=2, dec_heads=4), dict(dec_d_model=512, dec_layers=3, dec_heads=4, dec_ff_mult=4),
+                                 dict(dec_d_model=256, dec_layers=1, dec_heads=8, dec_ff_mult=3)])
+def test_one_token_decoder_kernels_match_the_tile_kernel_path(cuda, dec):
+    """dyn_decoder_steps (8 * layers + 2 lean launches per token: fused LayerNorm / embedding row-times-matrix kernel, one-query
+    attention, argmax into the token buffer) against the same decode through dyn_gemm_f32 / softmax / norm launches at M = 1
+    (`fused_decode = False`): the logits of EVERY step within 2e-5 of each other (both fp32, different summation order) when both
+    paths are fed the same prefix, the greedy ids equal wherever the top-2 margin is not a rounding tie, the sampled ids equal (same
+    counter-based draws), and the token ids independent of how many steps one call runs."""
+    import ctypes
+    from dynamic_asr_eval_amd import _lib
+    from dynamic_asr_eval_amd.enc_dec import EncDecSCConformerXL
+    from dynamic_asr_eval_amd.synthetic_weights import init_synthetic
+    cfg = dict(CFG, **dec)
+    hip = EncDecSCConformerXL(cfg, vocab_size=VOCAB + 3, device=cuda)
+    init_synthetic(hip, seed=21, blank_bias=1.0)
+    assert hip.fused_decode
+    x = torch.randn(1, 80, 640, generator=torch.Generator().manual_seed(9)).to(cuda)
+    enc = hip.forward(x)
+    n = 24
+    got = {}
+    for fused in (True, False):
+        hip.fused_decode = fused
+        got[fused] = [hip.generate(x, encoder_states=enc, max_tokens=n, check_every=e)["text_sequence"] for e in (1, 5, 64)]
+        assert got[fused][0] == got[fused][1] == got[fused][2]
+        hip._draws = 0
+        got[fused].append(hip.generate(x, encoder_states=enc, sample=True, temperature=0.9, seed=4, max_tokens=n)["text_sequence"])
+    # step-by-step logits on a common prefix (the tile-kernel path's own greedy ids)
+    prefix = got[False][0]
+    h = enc["hidden"][0]
+    dd, L = hip.dec["dec_d_model"], hip.dec["dec_layers"]
+    from dynamic_asr_eval_amd import ops
+    from dynamic_asr_eval_amd.enc_dec import DEC
+    with torch.no_grad(), ops.use_workspace(hip._scratch()):
+        kv = [ops.linear(h, hip.P[f"{DEC}layers.{l}.cross.kv.weight"], hip.P[f"{DEC}layers.{l}.cross.kv.bias"]) for l in range(L)]
+        caches = [[torch.zeros(len(prefix) + 2, 3 * dd, device=cuda) for _ in range(L)] for _ in range(2)]
+        tok = torch.zeros(len(prefix) + 3, dtype=torch.int32, device=cuda)
+        tok[1:len(prefix) + 1] = torch.tensor(prefix, dtype=torch.int32)
+        tok2 = tok.clone()
+        desc, keep = hip._decoder_desc(kv, caches[0], tok2, h.shape[0])
+        worst, flips = 0.0, 0
+        for t in range(len(prefix) + 1):
+            want = hip._decoder_step(tok, t, h, kv, caches[1])[0].clone()
+            _lib.check(_lib.load().dyn_decoder_steps(ctypes.byref(desc), t, 1, 0, 1.0, 0, 0, torch.cuda.current_stream().cuda_stream), "dyn_decoder_steps")
+            have = keep[1].clone()
+            worst = max(worst, float((have - want).abs().max()))
+            top = want.topk(2).values
+            if int(have.argmax()) != int(want.argmax()):
+                assert float(top[0] - top[1]) < 1e-5
+                flips += 1
+            tok2[t + 1] = tok[t + 1]                          # keep both on the common prefix
+        assert worst < 2e-5, worst
+        assert flips <= 1
+        for l in range(L):
+            torch.testing.assert_close(caches[0][l][:len(prefix) + 1], caches[1][l][:len(prefix) + 1], rtol=0, atol=2e-5)
+    if flips == 0:
+        assert got[True][0] == got[False][0] and got[True][3] == got[False][3]
+    assert len(got[False][0]) >= 3
+    # argument checks fail loudly
+    with pytest.raises(_lib.DynError):
+        _lib.check(_lib.load().dyn_decoder_steps(ctypes.byref(desc), hip.dec["dec_max_positions"] - 1, 2, 0, 1.0, 0, 0, 0), "dyn_decoder_steps")
+    with pytest.raises(_lib.DynError):
+        _lib.check(_lib.load().dyn_decoder_steps(ctypes.byref(desc), 0, 1, 1, 0.0, 0, 0, 0), "dyn_decoder_steps")
+
+
 def test_decoder_dropout_forward_and_every_gradient(cuda):
     """The three decoder dropout knobs (`dropout_emb`, `dropout_post_ff` -> ff_out_dropout, `dropout_attn` -> layer[0].fn.dropout_p;
     reference lcasr/lib.py:1511-1525,1636-1637) in training mode: loss and every gradient vs autograd with the same masks; in eval
