@@ -66,7 +66,6 @@ struct KParams {
     float* colsum;       // [M]: colsum[m] = colsum_beta * colsum[m] + sum_k A(m, k)   (bias gradient of a weight-gradient GEMM)
     float colsum_beta;
     int64_t first_item;  // first work item of this group in the grouped launch
-    int dbg;             // DIAGNOSTIC (DYN_GEMM_DEBUG): 3 = every workgroup fetches the operands of tile (0, 0); 4 = of its XCD's first tile
 };
 
 // alpha * acc + beta * c_in + bias in ONE pinned operation order (explicit mul / fma / add: no contraction differences between the
@@ -317,10 +316,8 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
     GldsStager<AK, BM> stA;
     GldsStager<BKM, BN> stB;
     if (GLDS) {
-        const int64_t lm0 = p.dbg == 3 ? 0 : (p.dbg == 4 ? (int64_t)(blockIdx.x & 7) * BM % (p.M - BM + 1) : m0);
-        const int64_t ln0 = p.dbg == 3 ? 0 : (p.dbg == 4 ? (int64_t)(blockIdx.x & 7) * BN % (p.N - BN + 1) : n0);
-        stA.init(A, p.lda, lm0, p.M, kbeg, wave, lane);
-        stB.init(B, p.ldb, ln0, p.N, kbeg, wave, lane);
+        stA.init(A, p.lda, m0, p.M, kbeg, wave, lane);
+        stB.init(B, p.ldb, n0, p.N, kbeg, wave, lane);
         if (nk > 0) { stA.issue(smem, wave); stB.issue(smem + SA, wave); }
     } else if (nk > 0) {
         fetch(kbeg);
@@ -731,13 +728,6 @@ void launch_vec(const KParams& kp, bool vec, dim3 grid, hipStream_t st) {
     static const bool allow_glds = [] { const char* e = getenv("DYN_GEMM_GLDS"); return !e || atoi(e) != 0; }();
     const bool glds = allow_glds && vec && kp.K % BK == 0 && kp.K > 0 && (!TA || kp.M % 4 == 0) && (TB || kp.N % 4 == 0) &&
                       (!TA || kp.M >= 4) && (TB || kp.N >= 4);
-    static const int dbg = [] { const char* e = getenv("DYN_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
-    if (glds && dbg) {
-        KParams k2 = kp;
-        k2.dbg = dbg;
-        hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true>), grid, dim3(NTHREADS), 0, st, k2);
-        return;
-    }
     if (glds) hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, true>), grid, dim3(NTHREADS), 0, st, kp);
     else if (vec) hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, true, false>), grid, dim3(NTHREADS), 0, st, kp);
     else hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, BM, BN, false, false>), grid, dim3(NTHREADS), 0, st, kp);
@@ -812,7 +802,7 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
     // the device-scope release / acquire fences write back and invalidate the XCD's whole L2 (buffer_wbl2 / buffer_inv sc1) under
     // every other kernel that shares it.  Kept because it is bit-identical and needs no second launch when a GEMM runs alone.
     kp.counters = (d->counters && n_ptiles > 0 && n_ptiles <= d->n_counters) ? d->counters : nullptr;
-    kp.colsum = nullptr; kp.colsum_beta = 0.f; kp.first_item = 0; kp.dbg = 0;
+    kp.colsum = nullptr; kp.colsum_beta = 0.f; kp.first_item = 0;
     const int64_t nblocks = pl.full_items + pl.tail_items * pl.tail_f;
     DYN_REQUIRE(nblocks < (1ll << 31) && tiles_m * tiles_n < (1ll << 31), DYN_E_ARG, "dyn_gemm_f32: grid too large (%lld workgroups)",
                 (long long)nblocks);
@@ -889,7 +879,7 @@ extern "C" int dyn_gemm_f32_grouped(const dyn_gemm_desc* descs, int32_t n, void*
         kp.full_items = kp.tiles_per_batch; kp.tail_f = 1; kp.tail_ws = nullptr;
         kp.epi = 0; kp.aux = nullptr; kp.counters = nullptr;
         kp.colsum = d->a_colsum; kp.colsum_beta = d->a_colsum_beta;
-        kp.first_item = total; kp.dbg = 0;
+        kp.first_item = total;
         total += kp.tiles_per_batch;
     }
     if (used == 0) return DYN_OK;
