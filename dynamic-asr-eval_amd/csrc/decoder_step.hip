@@ -5,8 +5,9 @@
 //   dec_gemv_kernel   y = act(W . f(x) + b) (+ residual): a wave per output row (coalesced 16-byte weight reads, one wave reduction per
 //                     row), x held in registers; f = LayerNorm (statistics recomputed per wave from the 1 - 8 KB row: cheaper than a
 //                     launch) and, for the first layer, the token-embedding + position gather itself
-//   dec_attn_kernel   one query against n cached keys / values, one workgroup per head: scores into LDS (16 lanes per key row),
-//                     softmax, weighted sum of the value rows
+//   dec_attn_kernel   one query against n cached keys / values, four workgroups per head (a quarter of the keys each): scores into LDS
+//                     (16 lanes per key row, four rows in flight), exponentials, weighted sum of the value rows; the four (sum, max,
+//                     denominator) triples are merged in the prologue of the projection that consumes them
 //   dec_pick_kernel   next token = argmax (or the Gumbel-max draw) over the logits, written straight into the token buffer
 // No tile kernel, no split-K reduce, no intermediate [1, n] score matrices in HBM.
 #include "common.h"
@@ -20,6 +21,8 @@ struct GemvArgs {
     const float* pos;      // EMBED: positional row [K]
     float* x_out;          // EMBED: the gathered row is written here once (the residual stream)
     int vocab;
+    const float* parts;    // MERGE: the key splits of the attention, [heads][NSPLIT][hd + 4] (unnormalised sum | max | denominator)
+    int hd;
     const float* gamma;    // LN
     const float* beta;
     float eps;
@@ -32,7 +35,9 @@ struct GemvArgs {
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-template <int NV, bool LN, bool SILU, bool EMBED>
+constexpr int NSPLIT = 4;   // key splits of the one-query attention (one workgroup each); merged in the consumer's prologue
+
+template <int NV, bool LN, bool SILU, bool EMBED, bool MERGE = false>
 __global__ __launch_bounds__(256) void dec_gemv_kernel(const GemvArgs a) {
     constexpr int K = NV * 256;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -50,6 +55,27 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const GemvArgs a) {
         if (blockIdx.x == 0 && w == 0) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) reinterpret_cast<float4*>(a.x_out)[lane + 64 * j] = xv[j];
+        }
+    } else if (MERGE) {     // x = softmax-weighted value sum of one head, put together from its NSPLIT key splits
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = 4 * (lane + 64 * j), h = c / a.hd, cc = c % a.hd;
+            const float* ph = a.parts + (int64_t)h * NSPLIT * (a.hd + 4);      // 16-byte aligned slots: hd | max | denominator | pad
+            float m = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < NSPLIT; ++u) m = fmaxf(m, ph[u * (a.hd + 4) + a.hd]);
+            float den = 0.f;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < NSPLIT; ++u) {
+                const float* pu = ph + u * (a.hd + 4);
+                const float wgt = __expf(pu[a.hd] - m);             // an empty split has max = -inf: weight 0
+                const float4 ov = *reinterpret_cast<const float4*>(pu + cc);
+                den += wgt * pu[a.hd + 1];
+                o.x += wgt * ov.x; o.y += wgt * ov.y; o.z += wgt * ov.z; o.w += wgt * ov.w;
+            }
+            const float r = 1.f / den;
+            xv[j] = make_float4(o.x * r, o.y * r, o.z * r, o.w * r);
         }
     } else {
 #pragma unroll
@@ -108,39 +134,59 @@ struct AttnArgs {
     const float* q;    // [heads * hd]
     const float* k;    // row j of head h at k + j * ld + h * hd
     const float* v;
-    float* out;        // [heads * hd]
+    float* parts;      // [heads][NSPLIT][hd + 4]: unnormalised weighted value sum | score maximum | sum of exponentials of this split's keys
     int n_keys, ld, hd;
     float scale;
 };
 
-// One query, one workgroup per head.  LDS: n_keys scores, then 256 partial sums.
+// One query; workgroup (h, s) takes the s-th quarter of the keys of head h.  LDS: the split's scores, then 256 partial sums.
 __global__ __launch_bounds__(256) void dec_attn_kernel(const AttnArgs a) {
     extern __shared__ float sc[];
     __shared__ float red[16];
     const int h = blockIdx.x, tid = threadIdx.x, g = tid >> 4, l = tid & 15;
-    const int hd = a.hd, n = a.n_keys;
+    const int hd = a.hd;
+    const int chunk = (a.n_keys + NSPLIT - 1) / NSPLIT;
+    const int j_lo = blockIdx.y * chunk;
+    const int n = min(chunk, a.n_keys - j_lo);       // keys of this split (<= 0: none)
+    float* out = a.parts + ((int64_t)h * NSPLIT + blockIdx.y) * (hd + 4);
+    if (n <= 0) {
+        if (tid < hd) out[tid] = 0.f;
+        if (tid == 0) { out[hd] = -INFINITY; out[hd + 1] = 0.f; }
+        return;
+    }
     const float* q = a.q + h * hd;
-    const float* k = a.k + h * hd;
-    const float* v = a.v + h * hd;
+    const float* k = a.k + (int64_t)j_lo * a.ld + h * hd;
+    const float* v = a.v + (int64_t)j_lo * a.ld + h * hd;
     float4 qv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = l * 4 + 64 * i;
         qv[i] = c < hd ? *reinterpret_cast<const float4*>(q + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int j = g; j < n; j += 16) {             // 16 lanes per key row
-        const float* kr = k + (int64_t)j * a.ld;
-        float s = 0.f;
+    // 16 lanes per key row, four rows in flight per 16-lane group (the loads of a group are independent: one latency per 64 keys)
+    for (int j0 = g; j0 < n; j0 += 64) {
+        float s[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = l * 4 + 64 * i;
-            if (c < hd) s += dot4(*reinterpret_cast<const float4*>(kr + c), qv[i]);
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 16 * u;
+            const float* kr = k + (int64_t)(j < n ? j : j0) * a.ld;
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = l * 4 + 64 * i;
+                if (c < hd) t += dot4(*reinterpret_cast<const float4*>(kr + c), qv[i]);
+            }
+            s[u] = t;
         }
-        s += __shfl_xor(s, 8, 64);
-        s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 1, 64);
-        if (l == 0) sc[j] = s * a.scale;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float t = s[u];
+            t += __shfl_xor(t, 8, 64);
+            t += __shfl_xor(t, 4, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 1, 64);
+            if (l == 0 && j0 + 16 * u < n) sc[j0 + 16 * u] = t * a.scale;
+        }
     }
     __syncthreads();
     float m = -INFINITY;
@@ -155,15 +201,26 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const AttnArgs a) {
     sum = dyn::block_sum(sum, red);               // its barriers also publish the exponentials
     const int c = tid % hd, kg = tid / hd, ng = 256 / hd;
     float acc = 0.f;
-    for (int j = kg; j < n; j += ng) acc += sc[j] * v[(int64_t)j * a.ld + c];
+    {   // eight value rows in flight per thread; the summation order (increasing j) does not depend on the unrolling
+        int j = kg;
+        for (; j + 7 * ng < n; j += 8 * ng) {
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = v[(int64_t)(j + u * ng) * a.ld + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += sc[j + u * ng] * vv[u];
+        }
+        for (; j < n; j += ng) acc += sc[j] * v[(int64_t)j * a.ld + c];
+    }
     float* part = sc + n;
     part[tid] = acc;
     __syncthreads();
     if (tid < hd) {
         float t = 0.f;
         for (int i = 0; i < ng; ++i) t += part[i * hd + tid];
-        a.out[h * hd + tid] = t / sum;
+        out[tid] = t;
     }
+    if (tid == 0) { out[hd] = m; out[hd + 1] = sum; }
 }
 
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
@@ -196,18 +253,18 @@ __global__ __launch_bounds__(1024) void dec_pick_kernel(const float* __restrict_
     }
 }
 
-template <bool LN, bool SILU, bool EMBED>
+template <bool LN, bool SILU, bool EMBED, bool MERGE = false>
 int launch_gemv(const GemvArgs& a, int K, hipStream_t st) {
     const dim3 grid((unsigned)dyn::cdiv(a.N, 4 * a.rpw)), blk(256);
     switch (K / 256) {
-        case 1: hipLaunchKernelGGL((dec_gemv_kernel<1, LN, SILU, EMBED>), grid, blk, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((dec_gemv_kernel<2, LN, SILU, EMBED>), grid, blk, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((dec_gemv_kernel<3, LN, SILU, EMBED>), grid, blk, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((dec_gemv_kernel<4, LN, SILU, EMBED>), grid, blk, 0, st, a); break;
-        case 5: hipLaunchKernelGGL((dec_gemv_kernel<5, LN, SILU, EMBED>), grid, blk, 0, st, a); break;
-        case 6: hipLaunchKernelGGL((dec_gemv_kernel<6, LN, SILU, EMBED>), grid, blk, 0, st, a); break;
-        case 7: hipLaunchKernelGGL((dec_gemv_kernel<7, LN, SILU, EMBED>), grid, blk, 0, st, a); break;
-        case 8: hipLaunchKernelGGL((dec_gemv_kernel<8, LN, SILU, EMBED>), grid, blk, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((dec_gemv_kernel<1, LN, SILU, EMBED, MERGE>), grid, blk, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((dec_gemv_kernel<2, LN, SILU, EMBED, MERGE>), grid, blk, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((dec_gemv_kernel<3, LN, SILU, EMBED, MERGE>), grid, blk, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((dec_gemv_kernel<4, LN, SILU, EMBED, MERGE>), grid, blk, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((dec_gemv_kernel<5, LN, SILU, EMBED, MERGE>), grid, blk, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((dec_gemv_kernel<6, LN, SILU, EMBED, MERGE>), grid, blk, 0, st, a); break;
+        case 7: hipLaunchKernelGGL((dec_gemv_kernel<7, LN, SILU, EMBED, MERGE>), grid, blk, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((dec_gemv_kernel<8, LN, SILU, EMBED, MERGE>), grid, blk, 0, st, a); break;
         default: return DYN_E_UNSUPPORTED;
     }
     return DYN_OK;
@@ -221,7 +278,7 @@ GemvArgs gemv(const float* x, const float* W, const float* bias, const float* re
     return a;
 }
 
-constexpr int MAX_KEYS = 12288;   // (n_keys + 256) floats of LDS <= 50 KB
+constexpr int MAX_KEYS = 4 * 12288;   // (n_keys / NSPLIT + 256) floats of LDS <= 50 KB
 
 }  // namespace
 
@@ -239,16 +296,21 @@ extern "C" int dyn_decoder_steps(const dyn_decoder_desc* d, int32_t t0, int32_t 
     DYN_REQUIRE((int64_t)t0 + n_steps <= d->max_positions, DYN_E_ARG, "dyn_decoder_steps: positions %d .. %d exceed max_positions %d", t0,
                 t0 + n_steps - 1, d->max_positions);
     DYN_REQUIRE(d->n_enc <= MAX_KEYS && t0 + n_steps <= MAX_KEYS, DYN_E_UNSUPPORTED, "dyn_decoder_steps: more than %d keys per attention", MAX_KEYS);
-    DYN_REQUIRE(d->scratch_floats >= (int64_t)3 * dd + ff, DYN_E_WORKSPACE, "dyn_decoder_steps: scratch %lld < %lld floats",
-                (long long)d->scratch_floats, (long long)3 * dd + ff);
+    const int64_t need = (int64_t)2 * dd + ff + (int64_t)H * NSPLIT * (hd + 4);
+    DYN_REQUIRE(d->scratch_floats >= need, DYN_E_WORKSPACE, "dyn_decoder_steps: scratch %lld < %lld floats", (long long)d->scratch_floats, (long long)need);
     DYN_REQUIRE(!sample || inv_temperature > 0.f, DYN_E_ARG, "dyn_decoder_steps: sampling needs a positive inverse temperature");
     for (int i = 0; i < L * DYN_DEC_PTRS_PER_LAYER; ++i)
         DYN_REQUIRE(d->layer_ptrs[i] != nullptr, DYN_E_ARG, "dyn_decoder_steps: layer pointer %d is null", i);
     hipStream_t st = (hipStream_t)stream;
     float* x = d->scratch;            // residual stream [dd]
     float* q2 = x + dd;               // cross-attention query [dd]
-    float* o = q2 + dd;               // attention output [dd]
-    float* act = o + dd;              // SiLU(w1 .) [ff]
+    float* act = q2 + dd;             // SiLU(w1 .) [ff]
+    float* parts = act + ff;          // key splits of the attention [H][NSPLIT][hd + 4]
+    auto merged = [&](const float* W, const float* bias) {      // x += W . attention + bias, the splits merged in the prologue
+        GemvArgs m = gemv(nullptr, W, bias, x, x, dd);
+        m.parts = parts; m.hd = hd;
+        return m;
+    };
     const float scale = 1.0f / sqrtf((float)hd);
     int rc = DYN_OK;
     for (int t = t0; t < t0 + n_steps && rc == DYN_OK; ++t) {
@@ -268,18 +330,18 @@ extern "C" int dyn_decoder_steps(const dyn_decoder_desc* d, int32_t t0, int32_t 
                 rc = launch_gemv<true, false, false>(a, dd, st);
             }
             if (rc != DYN_OK) break;
-            AttnArgs s{row, cache + dd, cache + 2 * dd, o, t + 1, 3 * dd, hd, scale};
-            hipLaunchKernelGGL(dec_attn_kernel, dim3(H), dim3(256), (size_t)(t + 1 + 256) * sizeof(float), st, s);
-            rc = launch_gemv<false, false, false>(gemv(o, F(4), F(5), x, x, dd), dd, st);
+            AttnArgs s{row, cache + dd, cache + 2 * dd, parts, t + 1, 3 * dd, hd, scale};
+            hipLaunchKernelGGL(dec_attn_kernel, dim3(H, NSPLIT), dim3(256), (size_t)(dyn::cdiv(t + 1, NSPLIT) + 256) * sizeof(float), st, s);
+            rc = launch_gemv<false, false, false, true>(merged(F(4), F(5)), dd, st);
             if (rc != DYN_OK) break;
             // cross-attention over the projected encoder rows
             a = gemv(x, F(8), F(9), nullptr, q2, dd);
             a.gamma = F(6); a.beta = F(7); a.eps = d->eps;
             rc = launch_gemv<true, false, false>(a, dd, st);
             if (rc != DYN_OK) break;
-            AttnArgs c{q2, ckv, ckv + dd, o, d->n_enc, 2 * dd, hd, scale};
-            hipLaunchKernelGGL(dec_attn_kernel, dim3(H), dim3(256), (size_t)(d->n_enc + 256) * sizeof(float), st, c);
-            rc = launch_gemv<false, false, false>(gemv(o, F(10), F(11), x, x, dd), dd, st);
+            AttnArgs c{q2, ckv, ckv + dd, parts, d->n_enc, 2 * dd, hd, scale};
+            hipLaunchKernelGGL(dec_attn_kernel, dim3(H, NSPLIT), dim3(256), (size_t)(dyn::cdiv(d->n_enc, NSPLIT) + 256) * sizeof(float), st, c);
+            rc = launch_gemv<false, false, false, true>(merged(F(10), F(11)), dd, st);
             if (rc != DYN_OK) break;
             // feed-forward
             a = gemv(x, F(14), nullptr, nullptr, act, ff);

@@ -214,7 +214,7 @@ class EncDecSCConformerXL(SCConformerXL):
             ptrs[l * DEC_PTRS_PER_LAYER + 16] = cache[l].data_ptr()
             ptrs[l * DEC_PTRS_PER_LAYER + 17] = kv[l].data_ptr()
         logits = torch.empty(self.vocab, device=self.device, dtype=torch.float32)
-        scratch = torch.empty(3 * dd + ff, device=self.device, dtype=torch.float32)
+        scratch = torch.empty(6 * dd + ff + 16 * dc["dec_heads"], device=self.device, dtype=torch.float32)
         d = DecoderDesc(d_model=dd, heads=dc["dec_heads"], d_ff=ff, vocab=self.vocab, layers=L, n_enc=int(n_enc),
                         max_positions=dc["dec_max_positions"], eps=float(self.config["norm_eps"]),
                         embed=P[DEC + "embed.weight"].data_ptr(), pos_table=self.pos_table.data_ptr(),

@@ -330,7 +330,7 @@ int dyn_gumbel_argmax_rows(const float* x, int64_t rows, int64_t C, int64_t ld, 
  *   ff.norm.weight, ff.norm.bias, ff.w1.weight [d_ff, d], ff.w2.weight [d, d_ff],
  *   cache [>= t0 + n_steps rows, 3d] (read / written), cross_kv [n_enc, 2d] (keys | values of the encoder states).
  * Limits: d_model % 256 == 0, d_model <= 2048, d_ff % 256 == 0, d_ff <= 2048, head dim a power of two in 4 .. 256,
- * t0 + n_steps <= max_positions, keys per attention <= 12288. */
+ * t0 + n_steps <= max_positions, keys per attention <= 49152. */
 #define DYN_DEC_PTRS_PER_LAYER 18
 typedef struct {
     int32_t d_model, heads, d_ff, vocab, layers, n_enc, max_positions, reserved_;
@@ -344,7 +344,7 @@ typedef struct {
     const void* const* layer_ptrs;
     int32_t* tokens;           /* device, >= t0 + n_steps + 1 entries; tokens[t0] must be valid on entry */
     float* logits;             /* device [vocab]: the logits of the last position run */
-    float* scratch;            /* device, >= 3 * d_model + d_ff floats */
+    float* scratch;            /* device, >= 6 * d_model + d_ff + 16 * heads floats */
     int64_t scratch_floats;
 } dyn_decoder_desc;
 int dyn_decoder_steps(const dyn_decoder_desc* d, int32_t t0, int32_t n_steps, int32_t sample, float inv_temperature, uint64_t seed,
