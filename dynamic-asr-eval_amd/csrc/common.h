@@ -74,6 +74,14 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Deferred column reductions (dyn_reduce_defer_begin / dyn_reduce_defer_flush, include/dyneval.h).  A kernel that leaves per-workgroup
+// partial sums takes their buffer from partials_alloc(): the caller's workspace as ever, or — while a deferral context is open on this
+// thread and has room — a slice of the context's arena, which nothing else touches before the flush.  reduce_or_defer() then launches the
+// reduction at once (partials in the workspace) or records it (partials in the arena).
+float* partials_alloc(void* workspace, int64_t bytes);
+void reduce_or_defer(const float* partial, float* out, int64_t P, int64_t n, float beta, hipStream_t st);
+void reduce_pair_or_defer(const float* p0, float* out0, const float* p1, float* out1, int64_t P, int64_t n, float beta, hipStream_t st);
+
 }  // namespace dyn
 
 #define DYN_REQUIRE(cond, code, ...)                         \

@@ -1,5 +1,6 @@
 // Error plumbing + identity queries of the C-ABI (see include/dyneval.h).
 #include "common.h"
+#include "reduce.h"
 #include <string.h>
 
 namespace dyn {
@@ -32,5 +33,170 @@ extern "C" int dyn_stream_destroy(void* stream) {
     DYN_REQUIRE(stream, DYN_E_ARG, "dyn_stream_destroy: null stream");
     hipError_t e = hipStreamDestroy((hipStream_t)stream);
     DYN_REQUIRE(e == hipSuccess, DYN_E_LAUNCH, "dyn_stream_destroy: %s", hipGetErrorString(e));
+    return DYN_OK;
+}
+
+// ---- deferred column reductions -------------------------------------------------------------------------------------------------
+// The reductions that end a backward kernel (LayerNorm / RMSNorm weight gradients, bias column sums) are launch-bound: ~7 us each for
+// a few hundred KB, ~55 per window of the adapt step, and (profiles/r03_trace_overlap_chains3.json) alone on the chip while they run.
+// Nothing reads their outputs before the optimiser, so between begin and flush they are recorded and then run as ONE launch per 96:
+// item e of the table is reduced by the workgroups (., e) with the arithmetic of reduce_partials_2d_kernel (16 row-lanes, lane order),
+// and items that accumulate into the SAME output (a shared parameter: the self-conditioning head's norm, six times per backward) form a
+// chain walked by the workgroups of its first item, value carried in a register — the same fp32 operations in the same order as the
+// separate launches: bit-identical.
+namespace dyn {
+namespace {
+struct ReduceItem {
+    const float* partial;
+    float* out;
+    int32_t P, n;
+    float beta;
+    int32_t next;    // next item of the same output (-1: none); >= 0 only on chain members
+    int32_t head;    // 1: first item of its chain (its workgroups walk the chain), 0: handled by the head's workgroups
+    int32_t pad_;
+};
+constexpr int kTable = 96;        // 96 * 40 B = 3.8 KB of kernel arguments
+struct ReduceTable { ReduceItem it[kTable]; };
+constexpr int kMaxItems = 1024;
+
+struct DeferState {
+    bool active = false;
+    char* arena = nullptr;
+    int64_t cap = 0, off = 0;
+    int n = 0;
+    ReduceItem items[kMaxItems];
+};
+thread_local DeferState g_defer;
+
+__global__ __launch_bounds__(1024) void reduce_partials_batched_kernel(const ReduceTable t) {
+    __shared__ float red[16][64];
+    int e = blockIdx.y;
+    if (!t.it[e].head) return;
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t n = t.it[e].n;
+    const int64_t col = (int64_t)blockIdx.x * 64 + cl;
+    if ((int64_t)blockIdx.x * 64 >= n) return;
+    float* out = t.it[e].out;
+    float carried = 0.f;
+    bool first = true;
+    while (e >= 0) {
+        const float* __restrict__ partial = t.it[e].partial;
+        const int64_t P = t.it[e].P;
+        const float beta = t.it[e].beta;
+        float s = 0.f;
+        if (col < n)
+            for (int64_t p = rl; p < P; p += 16) s += partial[p * n + col];
+        __syncthreads();                 // the previous chain member's sums have been read
+        red[rl][cl] = s;
+        __syncthreads();
+        if (rl == 0 && col < n) {
+            float tot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tot += red[k][cl];
+            const float prev = first ? (beta != 0.f ? out[col] : 0.f) : carried;
+            carried = (beta != 0.f ? beta * prev : 0.f) + tot;
+        }
+        first = false;
+        e = t.it[e].next;
+    }
+    if (rl == 0 && col < n) out[col] = carried;
+}
+
+void launch_batch(const ReduceItem* items, int count, hipStream_t st) {
+    ReduceTable t;
+    int64_t nmax = 0;
+    for (int i = 0; i < kTable; ++i) {
+        t.it[i] = i < count ? items[i] : ReduceItem{};
+        t.it[i].next = -1;
+        t.it[i].head = i < count ? 1 : 0;
+        if (i < count && items[i].n > nmax) nmax = items[i].n;
+    }
+    // link the chains (same output), in recording order
+    for (int i = 0; i < count; ++i) {
+        if (!t.it[i].head) continue;
+        int last = i;
+        for (int j = i + 1; j < count; ++j)
+            if (t.it[j].head && t.it[j].out == t.it[i].out) {
+                if (t.it[j].n != t.it[i].n) {       // never seen: one output reduced at two widths — run the batch item by item
+                    for (int k = 0; k < count; ++k) launch_reduce_partials(items[k].partial, items[k].out, items[k].P, items[k].n, items[k].beta, st);
+                    return;
+                }
+                t.it[last].next = j;
+                t.it[j].head = 0;
+                last = j;
+            }
+    }
+    hipLaunchKernelGGL(reduce_partials_batched_kernel, dim3((unsigned)cdiv(nmax, 64), (unsigned)count), dim3(1024), 0, st, t);
+}
+}  // namespace
+
+float* partials_alloc(void* workspace, int64_t bytes) {
+    DeferState& d = g_defer;
+    if (!d.active || bytes <= 0) return (float*)workspace;
+    const int64_t need = (bytes + 255) & ~(int64_t)255;
+    if (d.off + need > d.cap || d.n >= kMaxItems - 2) return (float*)workspace;     // no room: this reduction runs at once
+    float* p = (float*)(d.arena + d.off);
+    d.off += need;
+    return p;
+}
+
+static bool in_arena(const void* p) {
+    const DeferState& d = g_defer;
+    return d.active && (const char*)p >= d.arena && (const char*)p < d.arena + d.cap;
+}
+
+// run what has been recorded so far (recording order is execution order: a reduction that cannot be deferred must not overtake them)
+static void flush_recorded(hipStream_t st) {
+    DeferState& d = g_defer;
+    for (int i = 0; i < d.n; i += kTable) launch_batch(d.items + i, d.n - i < kTable ? d.n - i : kTable, st);
+    d.n = 0;
+}
+
+void reduce_or_defer(const float* partial, float* out, int64_t P, int64_t n, float beta, hipStream_t st) {
+    if (!in_arena(partial) || g_defer.n >= kMaxItems || P >= (1ll << 31) || n >= (1ll << 31)) {
+        if (g_defer.active && g_defer.n > 0) flush_recorded(st);
+        launch_reduce_partials(partial, out, P, n, beta, st);
+        return;
+    }
+    ReduceItem it{};
+    it.partial = partial; it.out = out; it.P = (int32_t)P; it.n = (int32_t)n; it.beta = beta; it.next = -1; it.head = 1;
+    g_defer.items[g_defer.n++] = it;
+}
+
+void reduce_pair_or_defer(const float* p0, float* out0, const float* p1, float* out1, int64_t P, int64_t n, float beta, hipStream_t st) {
+    if (!in_arena(p0) || !in_arena(p1) || g_defer.n + 2 > kMaxItems) {
+        if (g_defer.active && g_defer.n > 0) flush_recorded(st);
+        launch_reduce_partials_pair(p0, out0, p1, out1, P, n, beta, st);
+        return;
+    }
+    reduce_or_defer(p0, out0, P, n, beta, st);
+    reduce_or_defer(p1, out1, P, n, beta, st);
+}
+}  // namespace dyn
+
+extern "C" int dyn_reduce_defer_begin(void* arena, int64_t arena_bytes) {
+    DYN_REQUIRE(arena && arena_bytes >= 256 && (((uintptr_t)arena) & 255) == 0, DYN_E_ARG, "dyn_reduce_defer_begin: need a 256-byte aligned arena");
+    DYN_REQUIRE(!dyn::g_defer.active, DYN_E_ARG, "dyn_reduce_defer_begin: a deferral context is already open on this thread");
+    dyn::g_defer.active = true;
+    dyn::g_defer.arena = (char*)arena;
+    dyn::g_defer.cap = arena_bytes;
+    dyn::g_defer.off = 0;
+    dyn::g_defer.n = 0;
+    return DYN_OK;
+}
+
+extern "C" int dyn_reduce_defer_flush(void* stream) {
+    dyn::DeferState& d = dyn::g_defer;
+    if (!d.active) return DYN_OK;
+    d.active = false;
+    // batches of 96 in recording order; a chain cut by a batch boundary continues in the next launch, which the stream runs after this one
+    dyn::flush_recorded((hipStream_t)stream);
+    d.n = 0;
+    return dyn::check_launch("dyn_reduce_defer_flush");
+}
+
+extern "C" int dyn_reduce_defer_abort(void) {
+    dyn::g_defer.active = false;
+    dyn::g_defer.n = 0;
     return DYN_OK;
 }

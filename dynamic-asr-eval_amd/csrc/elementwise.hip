@@ -266,9 +266,9 @@ extern "C" int dyn_colsum(const float* x, float* out, int64_t rows, int64_t C, f
     hipStream_t st = (hipStream_t)stream;
     if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)workspace) & 15) == 0 && rows >= 256) {
         const int64_t ch = dyn::cdiv(rows, rpc);
-        hipLaunchKernelGGL(colsum_v4_partial_kernel, dim3((unsigned)dyn::cdiv(C, 256), (unsigned)ch), dim3(256), 0, st, x, (float*)workspace,
-                           rows, (int)C, rpc);
-        dyn::launch_reduce_partials((const float*)workspace, out, ch, C, beta, st);
+        float* part = dyn::partials_alloc(workspace, ch * C * (int64_t)sizeof(float));   // the workspace, or the open deferral context's arena
+        hipLaunchKernelGGL(colsum_v4_partial_kernel, dim3((unsigned)dyn::cdiv(C, 256), (unsigned)ch), dim3(256), 0, st, x, part, rows, (int)C, rpc);
+        dyn::reduce_or_defer(part, out, ch, C, beta, st);
         return dyn::check_launch("dyn_colsum");
     }
     if (rows <= 8192 && C >= 256) {  // enough column strips to occupy the chip: one launch instead of two

@@ -165,7 +165,7 @@ int launch_bwd(const float* x, const float* gamma, const float* mean, const floa
     if (dx_in == nullptr) dx_in = dx;
     const int nb = bwd_blocks(rows);
     DYN_REQUIRE(ws && ws_bytes >= (int64_t)2 * nb * C * (int64_t)sizeof(float), DYN_E_WORKSPACE, "norm_bwd: workspace too small");
-    float* pg = (float*)ws;
+    float* pg = dyn::partials_alloc(ws, (int64_t)2 * nb * C * (int64_t)sizeof(float));   // the workspace, or the open deferral context's arena
     float* pb = pg + (int64_t)nb * C;
     dim3 grid(nb), blk(256);
     switch (C / 256) {
@@ -176,10 +176,10 @@ int launch_bwd(const float* x, const float* gamma, const float* mean, const floa
         case 8: hipLaunchKernelGGL((norm_bwd_kernel<8, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in); break;
         default: dyn::set_error("norm: unsupported C=%lld", (long long)C); return DYN_E_UNSUPPORTED;
     }
-    if (!RMS && dgamma && dbeta) dyn::launch_reduce_partials_pair(pg, dgamma, pb, dbeta, (int64_t)nb, C, wbeta, st);
+    if (!RMS && dgamma && dbeta) dyn::reduce_pair_or_defer(pg, dgamma, pb, dbeta, (int64_t)nb, C, wbeta, st);
     else {
-        if (dgamma) dyn::launch_reduce_partials(pg, dgamma, (int64_t)nb, C, wbeta, st);
-        if (!RMS && dbeta) dyn::launch_reduce_partials(pb, dbeta, (int64_t)nb, C, wbeta, st);
+        if (dgamma) dyn::reduce_or_defer(pg, dgamma, (int64_t)nb, C, wbeta, st);
+        if (!RMS && dbeta) dyn::reduce_or_defer(pb, dbeta, (int64_t)nb, C, wbeta, st);
     }
     return dyn::check_launch("dyn_norm_bwd");
 }
@@ -243,14 +243,14 @@ extern "C" int dyn_chanaffine_bwd(const float* x, const float* mean, const float
     const int nb = chan_blocks(rows);
     DYN_REQUIRE(workspace && workspace_bytes >= dyn_chanaffine_bwd_workspace_bytes(rows, C), DYN_E_WORKSPACE,
                 "dyn_chanaffine_bwd: workspace too small");
-    float* pg = (float*)workspace;
+    float* pg = dyn::partials_alloc(workspace, (int64_t)2 * nb * C * (int64_t)sizeof(float));
     float* pb = pg + (int64_t)nb * C;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(chanaffine_bwd_kernel, dim3(nb), dim3(256), 0, st, x, mean, var, weight, dy, dx, dx_beta, pg, pb, rows, (int)C, eps);
-    if (dweight && dbias) dyn::launch_reduce_partials_pair(pg, dweight, pb, dbias, (int64_t)nb, C, wgrad_beta, st);
+    if (dweight && dbias) dyn::reduce_pair_or_defer(pg, dweight, pb, dbias, (int64_t)nb, C, wgrad_beta, st);
     else {
-        if (dweight) dyn::launch_reduce_partials(pg, dweight, (int64_t)nb, C, wgrad_beta, st);
-        if (dbias) dyn::launch_reduce_partials(pb, dbias, (int64_t)nb, C, wgrad_beta, st);
+        if (dweight) dyn::reduce_or_defer(pg, dweight, (int64_t)nb, C, wgrad_beta, st);
+        if (dbias) dyn::reduce_or_defer(pb, dbias, (int64_t)nb, C, wgrad_beta, st);
     }
     return dyn::check_launch("dyn_chanaffine_bwd");
 }

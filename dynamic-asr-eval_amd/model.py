@@ -182,6 +182,9 @@ class SCConformerXL:
         self.fused_subsampling = os.environ.get("DYN_FUSED_SUB", "1") != "0" and cfg["subsampling_conv_channels"] % 4 == 0
         # A/B switches (measurements only): DYN_FUSED_SILU=0 / DYN_GROUPED_WGRAD=0 restore the separate kernels / launches
         self.fused_silu = os.environ.get("DYN_FUSED_SILU", "0") != "0"        # SiLU / SiLU' in the epilogue of the producing GEMM: OFF
+        # the backward's launch-bound weight-gradient / bias-sum reductions as one launch at its end (DYN_DEFER_REDUCE=0: one launch each)
+        self.defer_reduces = os.environ.get("DYN_DEFER_REDUCE", "1") != "0"
+        self._defer_arena = None
         # by default (A/B on one box, 3 chains: 739 vs 738 audio-s/s, while the GEMM's own rate drops 110 -> 101 TFLOP/s: the
         # activation runs with the MFMA pipe idle, whereas the separate HBM-bound kernels hide under the other chains' GEMMs)
         self.grouped_wgrad = os.environ.get("DYN_GROUPED_WGRAD", "1") != "0"  # block weight gradients deferred to ONE grouped launch
@@ -306,6 +309,8 @@ class SCConformerXL:
         if self._ws is None:
             self._ws = torch.empty(ops.WORKSPACE_BYTES, dtype=torch.uint8, device=self.device)
             ops.counters(self._ws)          # zeroed arrival counters of this replica's GEMMs, allocated outside any graph capture
+            if self.defer_reduces:          # partial sums of the backward's deferred column reductions (ops.reduce_defer)
+                self._defer_arena = torch.empty(ops.DEFER_ARENA_BYTES, dtype=torch.uint8, device=self.device)
         return self._ws
 
     def forward(self, audio_signal):
@@ -541,7 +546,7 @@ class SCConformerXL:
 
     def _backward_graphed(self, grad_posteriors, n_active):
         G = self._graphs
-        key = (self._ctx_key, tuple(grad_posteriors.shape), n_active, frozenset(self.frozen), self.grouped_wgrad, self.fused_silu)
+        key = (self._ctx_key, tuple(grad_posteriors.shape), n_active, frozenset(self.frozen), self.grouped_wgrad, self.fused_silu, self.defer_reduces)
         ent = G["bwd"].get(key)
         if ent is None:
             static_g = grad_posteriors.contiguous().clone()
@@ -559,6 +564,15 @@ class SCConformerXL:
         return None
 
     def _backward(self, grad_posteriors, n_active, input_grad):
+        self._scratch()
+        with ops.reduce_defer(self._defer_arena if self.defer_reduces else None):
+            dx = self._backward_body(grad_posteriors, n_active, input_grad)
+        for name, _ in self.spec:                   # after the deferred reductions have been queued: they write gradients too
+            if not self.trainable(name):
+                self.G[name].zero_()
+        return dx
+
+    def _backward_body(self, grad_posteriors, n_active, input_grad):
         if self._ctx is None:
             raise ops.DynError("backward() without a grad-mode forward")
         static = self._ctx_static
@@ -622,9 +636,6 @@ class SCConformerXL:
         self._wq = None
         if not static:
             self._ctx = None
-        for name, _ in self.spec:
-            if not self.trainable(name):
-                self.G[name].zero_()
         return dx
 
     def _ff_bwd(self, dh, p, saved):

@@ -379,6 +379,32 @@ def axpby(x, y, a=1.0, b=1.0):
     return y
 
 
+DEFER_ARENA_BYTES = 160 << 20
+
+
+class reduce_defer:
+    """`with ops.reduce_defer(arena):` — the weight-gradient / bias-sum reductions of the backward kernels launched inside are recorded
+    and run as one launch per 96 at exit (dyn_reduce_defer_begin / _flush; bit-identical).  Nothing inside may read those gradients; the
+    block must not span a `yield` (the context is per host thread).  `arena=None`: no deferral."""
+
+    def __init__(self, arena):
+        self.arena = arena
+
+    def __enter__(self):
+        if self.arena is not None:
+            check(_L().dyn_reduce_defer_begin(self.arena.data_ptr(), self.arena.numel()), "dyn_reduce_defer_begin")
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if self.arena is None:
+            return False
+        if exc_type is not None:
+            _L().dyn_reduce_defer_abort()
+            return False
+        check(_L().dyn_reduce_defer_flush(_stream()), "dyn_reduce_defer_flush")
+        return False
+
+
 def colsum(x, out, beta=1.0):
     """out[C] = beta * out + sum over rows of x[rows, C]."""
     _cc(x, "colsum.x"); _cc(out, "colsum.out")

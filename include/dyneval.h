@@ -106,6 +106,16 @@ int64_t dyn_colsum_workspace_bytes(int64_t rows, int64_t C);
 int dyn_colsum(const float* x, float* out, int64_t rows, int64_t C, float beta, void* workspace, int64_t workspace_bytes,
                void* stream);
 int dyn_reduce_partials(const float* partial, float* out, int64_t P, int64_t n, float beta, void* stream);
+/* Deferred column reductions.  The reductions that end dyn_layernorm_bwd / dyn_layernorm_bwd_res / dyn_rmsnorm_bwd / dyn_chanaffine_bwd (weight gradients) and
+ * dyn_colsum (bias gradients) are launch-bound (~7 us for a few hundred KB, ~55 per window of the adapt step) and nothing reads their
+ * outputs before the optimiser step (`loss.backward()` ... `optimizer.step()`, reference lcasr/lib.py:579-581).  Between begin and flush
+ * (thread-local, not nestable) those entry points keep their partial sums in `arena` (256-byte aligned, untouched by anything else until
+ * the flush) and only RECORD the reduction; flush runs the recorded ones as one launch per 96, each with the per-column summation order
+ * of the separate launch, reductions into the same output chained in recording order: bit-identical results.  When the arena is full the
+ * entry points fall back to reducing at once.  abort drops the context without launching (error paths). */
+int dyn_reduce_defer_begin(void* arena, int64_t arena_bytes);
+int dyn_reduce_defer_flush(void* stream);
+int dyn_reduce_defer_abort(void);
 /* [F, T] (row stride ldx) -> [T, F]: a log-mel window enters the encoder channels-last */
 int dyn_transpose_ft(const float* x, float* y, int64_t F, int64_t T, int64_t ldx, void* stream);
 

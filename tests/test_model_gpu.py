@@ -438,6 +438,39 @@ def test_fused_subsampling_matches_the_separate_kernels_through_the_model(cuda):
     assert (grads[0] - grads[1]).abs().max().item() / denom < 1e-5
 
 
+@pytest.mark.parametrize("cfg_over", [{}, dict(conv_norm="layer_norm", n_layers=3), dict(self_conditioning=False)])
+def test_deferred_reductions_are_bit_identical_through_the_model(cuda, cfg_over):
+    """model.defer_reduces (default): the weight-gradient / bias-sum reductions of the backward run as one batched launch at its end
+    (dyn_reduce_defer_begin / _flush) — every gradient bit-identical to one launch per reduction, with the shared self-conditioning norm
+    (several reductions chained into one output), with frozen parameters (their gradients stay zero), eagerly and through the hipGraph."""
+    from dynamic_asr_eval_amd.lib import freeze_subsampling
+    ref, hip = _pair(cuda, dict(SMALL, **cfg_over), vocab=128)
+    assert hip.defer_reduces
+    x = torch.randn(2, 80, 300, generator=torch.Generator().manual_seed(12)).to(cuda)
+    for frozen in (False, True):
+        if frozen:
+            freeze_subsampling(hip)
+        for n_active in (None, 1):
+            grads = []
+            for defer, graphs in ((True, False), (False, False), (True, True), (True, True)):
+                hip.defer_reduces, hip.use_graphs = defer, graphs
+                with torch.enable_grad():
+                    out = hip(audio_signal=x)['final_posteriors']
+                nb = out.shape[0] if n_active is None else n_active
+                gp = torch.randn(out[:nb].shape, generator=torch.Generator().manual_seed(13)).to(cuda) / out[0].numel()
+                hip.zero_grad()
+                hip.backward(gp, n_active=n_active)
+                grads.append(hip.flat_grads.clone())
+            hip.defer_reduces, hip.use_graphs = True, False
+            assert grads[0].abs().max().item() > 0
+            for g in grads[1:]:
+                assert torch.equal(grads[0], g)
+            if frozen:
+                for name, _ in hip.spec:
+                    if not hip.trainable(name):
+                        assert float(hip.G[name].abs().max()) == 0.0, name
+
+
 def test_clean_copy_attention_through_the_fused_kernel(cuda):
     """model.grad_samples = 1 (what lib.dynamic_eval sets: only the augmented copy is differentiated, reference lcasr/lib.py:570-575):
     the clean copy's attention takes the fused no-grad kernel inside the grad-mode batch.  Same posteriors (fp32 summation order

@@ -431,3 +431,55 @@ def test_fused_attention_grad_mode_forward_and_backward(cuda, B, T, H):
     assert err < 2e-5, err
     again = ops.attention_bwd(qkv.to(cuda), out, dout.to(cuda), lse, B, T, H, D, scale)
     assert torch.equal(dqkv, again)
+
+
+def test_deferred_column_reductions_match_the_separate_launches(cuda):
+    """dyn_reduce_defer_begin / _flush: LayerNorm / RMSNorm / BatchRenorm weight gradients and bias column sums recorded and reduced in one
+    batched launch — bit-identical to reducing at once, including reductions chained into one output (beta = 1, a shared parameter),
+    beta = 0 overwrites, more than 96 recorded reductions (two launches), and an arena too small for everything (the rest reduces at once)."""
+    from dynamic_asr_eval_amd import ops
+    g = torch.Generator().manual_seed(5)
+    rows, C = 1100, 768
+    xs = [torch.randn(rows, C, generator=g).to(cuda) for _ in range(3)]
+    dys = [torch.randn(rows, C, generator=g).to(cuda) for _ in range(3)]
+    gam = torch.randn(C, generator=g).to(cuda)
+    bet = torch.randn(C, generator=g).to(cuda)
+    wide = torch.randn(900, 3072, generator=g).to(cuda)
+
+    def run(arena, repeats):
+        out = {}
+        dgam, dbet = torch.full((C,), 0.25, device=cuda), torch.full((C,), -0.5, device=cuda)
+        drms = torch.zeros(C, device=cuda)
+        dw, db = torch.ones(C, device=cuda), torch.ones(C, device=cuda)
+        bias_w = torch.full((3072,), 2.0, device=cuda)
+        bias_c = torch.zeros(C, device=cuda)
+        with ops.reduce_defer(arena):
+            for r in range(repeats):
+                for x, dy in zip(xs, dys):
+                    y, mean, rstd = ops.layernorm(x, gam, bet)
+                    ops.layernorm_bwd(x, gam, mean, rstd, dy, torch.empty_like(x), dgam, dbet, wgrad_beta=1.0)      # chained into one output
+                    y2, rs = ops.rmsnorm(x, gam)
+                    ops.rmsnorm_bwd(x, gam, rs, dy, torch.empty_like(x), drms, wgrad_beta=0.0 if r == 0 and x is xs[0] else 1.0)
+                    ops.colsum(dy, bias_c, beta=1.0)
+                ops.colsum(wide, bias_w, beta=0.5)
+                var = torch.rand(C, generator=torch.Generator().manual_seed(3)).to(cuda) + 0.5
+                ops.chanaffine_bwd(xs[0], bet, var, gam, dys[0], torch.empty_like(xs[0]), dw, db, wgrad_beta=1.0)
+        out.update(dgam=dgam, dbet=dbet, drms=drms, dw=dw, db=db, bias_w=bias_w, bias_c=bias_c)
+        return out
+
+    with ops.use_workspace(torch.empty(ops.WORKSPACE_BYTES // 4, dtype=torch.uint8, device=cuda)):
+        for repeats in (1, 9):                      # 9 x 14 = 126 recorded reductions: two batched launches
+            want = run(None, repeats)
+            for arena_bytes in (ops.DEFER_ARENA_BYTES, 5 << 20):
+                got = run(torch.empty(arena_bytes, dtype=torch.uint8, device=cuda), repeats)
+                for k in want:
+                    assert torch.equal(want[k], got[k]), (k, repeats, arena_bytes)
+        assert float(want["dgam"].abs().max()) > 1.0
+    # a context is per thread and not nestable; an exception inside drops it
+    a = torch.empty(1 << 20, dtype=torch.uint8, device=cuda)
+    with pytest.raises(ops.DynError):
+        with ops.reduce_defer(a):
+            with ops.reduce_defer(a):
+                pass
+    with ops.reduce_defer(a):
+        pass
