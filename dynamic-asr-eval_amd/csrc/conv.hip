@@ -779,7 +779,7 @@ extern "C" int dyn_dwconv1d_wgrad(const float* x, const float* dy, float* dw, fl
     const int64_t chunks = wgrad_tiles(B, T, &per), tiles = chunks * B;
     DYN_REQUIRE(workspace && workspace_bytes >= tiles * C * (KW + 1) * (int64_t)sizeof(float), DYN_E_WORKSPACE,
                 "dyn_dwconv1d_wgrad: workspace too small");
-    float* pw = (float*)workspace;
+    float* pw = dyn::partials_alloc(workspace, tiles * C * (KW + 1) * (int64_t)sizeof(float));   // the workspace, or the open deferral context's arena
     float* pb = pw + tiles * C * KW;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)chunks, (unsigned)dyn::cdiv(C, 256), (unsigned)B), blk(256);
@@ -790,8 +790,8 @@ extern "C" int dyn_dwconv1d_wgrad(const float* x, const float* dy, float* dw, fl
         default: dyn::set_error("dwconv1d_wgrad: unsupported kernel width %lld", (long long)KW); return DYN_E_UNSUPPORTED;
     }
 #undef GO
-    dyn::launch_reduce_partials(pw, dw, tiles, C * KW, beta, st);
-    if (dbias) dyn::launch_reduce_partials(pb, dbias, tiles, C, beta, st);
+    dyn::reduce_or_defer(pw, dw, tiles, C * KW, beta, st);
+    if (dbias) dyn::reduce_or_defer(pb, dbias, tiles, C, beta, st);
     return dyn::check_launch("dyn_dwconv1d_wgrad");
 }
 
