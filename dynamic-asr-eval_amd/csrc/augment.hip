@@ -37,10 +37,17 @@ __global__ __launch_bounds__(TPB) void moments_partial_kernel(const float* __res
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = (double)s; partial[2 * blockIdx.x + 1] = (double)q; }
 }
 
+// one wave: lane l adds the partials l, l + 64, ... (independent loads), then a fixed butterfly over the lanes — deterministic
 __global__ void moments_final_kernel(const double* __restrict__ partial, int nb, int64_t n, float* __restrict__ out3) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
     double s = 0.0, q = 0.0;
-    for (int i = 0; i < nb; ++i) { s += partial[2 * i]; q += partial[2 * i + 1]; }
+    for (int i = threadIdx.x; i < nb; i += 64) { s += partial[2 * i]; q += partial[2 * i + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if (threadIdx.x != 0) return;
     const double mean = s / (double)n;
     const double var = n > 1 ? (q - s * mean) / (double)(n - 1) : 0.0;  // unbiased, as torch.std()
     out3[0] = (float)s;

@@ -98,7 +98,7 @@ struct CtcDims {
 };
 
 // Per sample: skip_ok[s] (the s-2 transition is allowed) and next_same[k] (next target index with the same label).
-__global__ __launch_bounds__(256) void ctc_prep_kernel(const int32_t* __restrict__ targets, const int32_t* __restrict__ tlen,
+__global__ __launch_bounds__(1024) void ctc_prep_kernel(const int32_t* __restrict__ targets, const int32_t* __restrict__ tlen,
                                                         int32_t* __restrict__ next_same, int32_t* __restrict__ is_first,
                                                         int64_t S_max) {
     // the target row is staged in LDS once: the two scans below are O(S^2) reads of it (S is a few hundred labels per window;
@@ -109,16 +109,26 @@ __global__ __launch_bounds__(256) void ctc_prep_kernel(const int32_t* __restrict
     const int32_t* tg = targets + b * S_max;
     for (int k = threadIdx.x; k < S; k += blockDim.x) tg_s[k] = tg[k];
     __syncthreads();
-    for (int k = threadIdx.x; k < S; k += blockDim.x) {
+    // one wave per label position k, 64 candidate positions compared per step (ballot): with mostly distinct labels both searches run to
+    // the end of the row, S / 64 steps instead of S dependent LDS reads per position
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int k = w; k < S; k += nw) {
         const int c = tg_s[k];
         int nx = -1;
-        for (int j = k + 1; j < S; ++j)
-            if (tg_s[j] == c) { nx = j; break; }
-        next_same[b * S_max + k] = nx;
+        for (int j0 = k + 1; j0 < S; j0 += 64) {
+            const int j = j0 + lane;
+            const unsigned long long hit = __ballot(j < S && tg_s[j] == c);
+            if (hit) { nx = j0 + __ffsll((long long)hit) - 1; break; }
+        }
         int first = 1;
-        for (int j = 0; j < k; ++j)
-            if (tg_s[j] == c) { first = 0; break; }
-        is_first[b * S_max + k] = first;
+        for (int j0 = 0; j0 < k; j0 += 64) {
+            const int j = j0 + lane;
+            if (__ballot(j < k && tg_s[j] == c)) { first = 0; break; }
+        }
+        if (lane == 0) {
+            next_same[b * S_max + k] = nx;
+            is_first[b * S_max + k] = first;
+        }
     }
 }
 
@@ -418,7 +428,7 @@ extern "C" int dyn_ctc_loss(const float* log_probs, int64_t T, int64_t B, int64_
     CtcDims d;
     d.T_max = T; d.B = B; d.C = C; d.lp_st = lp_stride_t; d.lp_sb = lp_stride_b; d.S_max = Sm; d.L_max = L; d.blank = blank;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(ctc_prep_kernel, dim3((unsigned)B), dim3(256), (size_t)Sm * sizeof(int32_t), st, targets, target_lengths, w.next_same, w.is_first, Sm);
+    hipLaunchKernelGGL(ctc_prep_kernel, dim3((unsigned)B), dim3(1024), (size_t)Sm * sizeof(int32_t), st, targets, target_lengths, w.next_same, w.is_first, Sm);
     hipLaunchKernelGGL(ctc_gather_kernel, dim3((unsigned)T, (unsigned)B), dim3(256), 0, st, log_probs, targets, input_lengths,
                        target_lengths, w.slab, d);
     int threads = (int)((L + 63) / 64 * 64);

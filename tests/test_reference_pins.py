@@ -70,7 +70,9 @@ def test_oracle_stitch_reproduces_the_reference_statements(pins, tag):
         C, rows = case["classes"], case["acc_rows"]
         out = stitch_ref(mo, torch.zeros(1, rows, C), torch.zeros(1, rows, C))[0].numpy()
         want = arr[f"stitch_{tag}_{ci}_out"]
-        assert out.shape == want.shape == (case["out_rows"], C) and np.array_equal(out, want), (tag, ci)
+        # equal to the last bit on the machine that made the pins; another CPU's vectorised log may differ in the last place
+        assert out.shape == want.shape == (case["out_rows"], C) and np.abs(out - want).max() <= 1e-6 and \
+            np.array_equal(out.argmax(-1), want.argmax(-1)), (tag, ci)
 
 
 def test_fetch_utterances_reproduces_the_reference(pins, tmp_path):
