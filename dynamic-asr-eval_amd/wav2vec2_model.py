@@ -10,6 +10,7 @@ Parameter NAMES are HF's (state_dict interchange with transformers, which is the
 of conv kernels is [C_out][kernel][C_in] so each strided Conv1d is one implicit GEMM over overlapping rows of the
 channels-last activation (ops.conv1d), converted on load / save."""
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -52,6 +53,7 @@ class Wav2Vec2ForCTC:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ops.DynError("Wav2Vec2ForCTC runs only on the HIP path (device must be cuda)")
+        self._defer_arena = None
         H = c["hidden_size"]
         assert H % 256 == 0 and c["conv_dim"][-1] % 256 == 0, "LayerNorm kernels need C % 256 == 0"
         spec, self._conv = [("wav2vec2.masked_spec_embed", (H,), None)], {}
@@ -248,7 +250,18 @@ class Wav2Vec2ForCTC:
         return ops.linear_dgrad(dy, self.P[wname]) if need_dx else None
 
     def backward(self, grad_logits, n_active=None):
-        """Accumulates dL/dparam into flat_grads given dL/dlogits [nb, T', V] for the first nb samples of the batch."""
+        """Accumulates dL/dparam into flat_grads given dL/dlogits [nb, T', V] for the first nb samples of the batch.  The launch-bound
+        column reductions of the norm / bias gradients run as one batched launch at the end (ops.reduce_defer; bit-identical)."""
+        if self._defer_arena is None and os.environ.get("DYN_DEFER_REDUCE", "1") != "0":
+            self._defer_arena = torch.empty(ops.DEFER_ARENA_BYTES, dtype=torch.uint8, device=self.device)
+        with ops.reduce_defer(self._defer_arena):
+            self._backward_body(grad_logits, n_active)
+        for name in self.frozen:                    # after the deferred reductions have been queued: they write gradients too
+            for n, _, _ in self.spec:
+                if n.startswith(name):
+                    self.G[n].zero_()
+
+    def _backward_body(self, grad_logits, n_active=None):
         ctx = self._ctx
         if ctx is None:
             raise ops.DynError("backward() without a grad-mode forward")
@@ -356,7 +369,3 @@ class Wav2Vec2ForCTC:
                 da = ops.conv1d_dgrad(dz, wmat, a_in.shape[1], a_in.shape[2], k, s)
             ctx["conv"][i] = None
         self._ctx = None
-        for name in self.frozen:
-            for n, _, _ in self.spec:
-                if n.startswith(name):
-                    self.G[n].zero_()
