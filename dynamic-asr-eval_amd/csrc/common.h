@@ -80,6 +80,7 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // reduction at once (partials in the workspace) or records it (partials in the arena).
 float* partials_alloc(void* workspace, int64_t bytes);
 void reduce_or_defer(const float* partial, float* out, int64_t P, int64_t n, float beta, hipStream_t st);
+void reduce_taps_or_defer(const float* partial, float* out, int64_t P, int64_t n, float beta, int C, hipStream_t st);   // [tap][C] -> [C][taps]
 void reduce_pair_or_defer(const float* p0, float* out0, const float* p1, float* out1, int64_t P, int64_t n, float beta, hipStream_t st);
 
 }  // namespace dyn

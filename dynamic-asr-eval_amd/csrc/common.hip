@@ -53,7 +53,7 @@ struct ReduceItem {
     float beta;
     int32_t next;    // next item of the same output (-1: none); >= 0 only on chain members
     int32_t head;    // 1: first item of its chain (its workgroups walk the chain), 0: handled by the head's workgroups
-    int32_t pad_;
+    int32_t taps_c;  // > 0: partial columns are laid out [tap][C], the output [C][taps] (reduce_partials_2d_taps_kernel); 0: same order
 };
 constexpr int kTable = 96;        // 96 * 40 B = 3.8 KB of kernel arguments
 struct ReduceTable { ReduceItem it[kTable]; };
@@ -77,6 +77,8 @@ __global__ __launch_bounds__(1024) void reduce_partials_batched_kernel(const Red
     const int64_t col = (int64_t)blockIdx.x * 64 + cl;
     if ((int64_t)blockIdx.x * 64 >= n) return;
     float* out = t.it[e].out;
+    const int64_t tc = t.it[e].taps_c;
+    const int64_t ocol = tc > 0 ? (col % tc) * (n / tc) + col / tc : col;      // the same for every member of a chain
     float carried = 0.f;
     bool first = true;
     while (e >= 0) {
@@ -93,13 +95,13 @@ __global__ __launch_bounds__(1024) void reduce_partials_batched_kernel(const Red
             float tot = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) tot += red[k][cl];
-            const float prev = first ? (beta != 0.f ? out[col] : 0.f) : carried;
+            const float prev = first ? (beta != 0.f ? out[ocol] : 0.f) : carried;
             carried = (beta != 0.f ? beta * prev : 0.f) + tot;
         }
         first = false;
         e = t.it[e].next;
     }
-    if (rl == 0 && col < n) out[col] = carried;
+    if (rl == 0 && col < n) out[ocol] = carried;
 }
 
 void launch_batch(const ReduceItem* items, int count, hipStream_t st) {
@@ -117,8 +119,11 @@ void launch_batch(const ReduceItem* items, int count, hipStream_t st) {
         int last = i;
         for (int j = i + 1; j < count; ++j)
             if (t.it[j].head && t.it[j].out == t.it[i].out) {
-                if (t.it[j].n != t.it[i].n) {       // never seen: one output reduced at two widths — run the batch item by item
-                    for (int k = 0; k < count; ++k) launch_reduce_partials(items[k].partial, items[k].out, items[k].P, items[k].n, items[k].beta, st);
+                if (t.it[j].n != t.it[i].n || t.it[j].taps_c != t.it[i].taps_c) {       // never seen: one output reduced at two widths — run the batch item by item
+                    for (int k = 0; k < count; ++k) {
+                        if (items[k].taps_c > 0) launch_reduce_partials_taps(items[k].partial, items[k].out, items[k].P, items[k].n, items[k].beta, items[k].taps_c, st);
+                        else launch_reduce_partials(items[k].partial, items[k].out, items[k].P, items[k].n, items[k].beta, st);
+                    }
                     return;
                 }
                 t.it[last].next = j;
@@ -160,6 +165,17 @@ void reduce_or_defer(const float* partial, float* out, int64_t P, int64_t n, flo
     }
     ReduceItem it{};
     it.partial = partial; it.out = out; it.P = (int32_t)P; it.n = (int32_t)n; it.beta = beta; it.next = -1; it.head = 1;
+    g_defer.items[g_defer.n++] = it;
+}
+
+void reduce_taps_or_defer(const float* partial, float* out, int64_t P, int64_t n, float beta, int C, hipStream_t st) {
+    if (!in_arena(partial) || g_defer.n >= kMaxItems || P >= (1ll << 31) || n >= (1ll << 31)) {
+        if (g_defer.active && g_defer.n > 0) flush_recorded(st);
+        launch_reduce_partials_taps(partial, out, P, n, beta, C, st);
+        return;
+    }
+    ReduceItem it{};
+    it.partial = partial; it.out = out; it.P = (int32_t)P; it.n = (int32_t)n; it.beta = beta; it.next = -1; it.head = 1; it.taps_c = C;
     g_defer.items[g_defer.n++] = it;
 }
 

@@ -891,17 +891,17 @@ extern "C" int dyn_sub12_bwd(const float* x, const float* du2, const float* w1, 
     const int64_t chunks = wgrad_tiles2d(T1, &per), tiles = chunks * B, wgs = dyn::cdiv(tiles, 4);
     DYN_REQUIRE(workspace && workspace_bytes >= wgs * C * 20 * (int64_t)sizeof(float) && (((uintptr_t)workspace) & 15) == 0, DYN_E_WORKSPACE,
                 "dyn_sub12_bwd: workspace too small");
-    float* pw1 = (float*)workspace;
+    float* pw1 = dyn::partials_alloc(workspace, wgs * C * 20 * (int64_t)sizeof(float));   // the workspace, or the open deferral context's arena
     float* pb1 = pw1 + wgs * C * 9;
     float* pw2 = pb1 + wgs * C;
     float* pb2 = pw2 + wgs * C * 9;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sub12_bwd_kernel, dim3((unsigned)wgs), dim3(256), 0, st, x, du2, w1, b1, w2, pw1, pb1, pw2, pb2, T, (int)F, T1, (int)F1,
                        T2, (int)F2, (int)C, per, chunks, tiles);
-    dyn::launch_reduce_partials_taps(pw1, dw1, wgs, C * 9, beta, (int)C, st);
-    dyn::launch_reduce_partials(pb1, db1, wgs, C, beta, st);
-    dyn::launch_reduce_partials_taps(pw2, dw2, wgs, C * 9, beta, (int)C, st);
-    dyn::launch_reduce_partials(pb2, db2, wgs, C, beta, st);
+    dyn::reduce_taps_or_defer(pw1, dw1, wgs, C * 9, beta, (int)C, st);
+    dyn::reduce_or_defer(pb1, db1, wgs, C, beta, st);
+    dyn::reduce_taps_or_defer(pw2, dw2, wgs, C * 9, beta, (int)C, st);
+    dyn::reduce_or_defer(pb2, db2, wgs, C, beta, st);
     return dyn::check_launch("dyn_sub12_bwd");
 }
 
@@ -946,14 +946,15 @@ extern "C" int dyn_dwconv2d_s2_wgrad(const float* z, const float* du, float* dw,
     const int64_t chunks = wgrad_tiles2d(To, &per), tiles = chunks * B;
     DYN_REQUIRE(workspace && workspace_bytes >= tiles * C * 10 * (int64_t)sizeof(float), DYN_E_WORKSPACE,
                 "dyn_dwconv2d_s2_wgrad: workspace too small");
-    float* pw = (float*)workspace;
+    const bool v4 = C % 4 == 0 && ((((uintptr_t)z) | ((uintptr_t)du)) & 15) == 0;
+    float* pw = v4 ? dyn::partials_alloc(workspace, tiles * C * 10 * (int64_t)sizeof(float)) : (float*)workspace;
     float* pb = pw + tiles * C * 9;
     hipStream_t st = (hipStream_t)stream;
-    if (C % 4 == 0 && ((((uintptr_t)z) | ((uintptr_t)du)) & 15) == 0) {
+    if (v4) {
         hipLaunchKernelGGL((conv2d_s2_wgrad_v4_kernel<false>), dim3((unsigned)dyn::cdiv(tiles, 4)), dim3(256), 0, st, z, du, pw, pb, T, (int)F,
                            To, (int)Fo, (int)C, per, chunks, tiles);
-        dyn::launch_reduce_partials_taps(pw, dw, dyn::cdiv(tiles, 4), C * 9, beta, (int)C, st);
-        dyn::launch_reduce_partials(pb, dbias, dyn::cdiv(tiles, 4), C, beta, st);
+        dyn::reduce_taps_or_defer(pw, dw, dyn::cdiv(tiles, 4), C * 9, beta, (int)C, st);
+        dyn::reduce_or_defer(pb, dbias, dyn::cdiv(tiles, 4), C, beta, st);
         return dyn::check_launch("dyn_dwconv2d_s2_wgrad");
     } else {
         dim3 grid((unsigned)chunks, (unsigned)dyn::cdiv(C, 256), (unsigned)B);

@@ -107,7 +107,7 @@ int dyn_colsum(const float* x, float* out, int64_t rows, int64_t C, float beta, 
                void* stream);
 int dyn_reduce_partials(const float* partial, float* out, int64_t P, int64_t n, float beta, void* stream);
 /* Deferred column reductions.  The reductions that end dyn_layernorm_bwd / dyn_layernorm_bwd_res / dyn_rmsnorm_bwd / dyn_chanaffine_bwd (weight gradients) and
- * dyn_colsum (bias gradients) / dyn_dwconv1d_wgrad (depthwise taps) are launch-bound (~7 us for a few hundred KB, ~55 per window of the adapt step) and nothing reads their
+ * dyn_colsum (bias gradients) / dyn_dwconv1d_wgrad, dyn_dwconv2d_s2_wgrad, dyn_sub12_bwd (convolution taps) are launch-bound (~7 us for a few hundred KB, ~55 per window of the adapt step) and nothing reads their
  * outputs before the optimiser step (`loss.backward()` ... `optimizer.step()`, reference lcasr/lib.py:579-581).  Between begin and flush
  * (thread-local, not nestable) those entry points keep their partial sums in `arena` (256-byte aligned, untouched by anything else until
  * the flush) and only RECORD the reduction; flush runs the recorded ones as one launch per 96, each with the per-column summation order
