@@ -74,8 +74,10 @@ class Wav2Vec2ForCTC:
         spec += [("wav2vec2.encoder.layer_norm.weight", (H,), None), ("wav2vec2.encoder.layer_norm.bias", (H,), None)]
         for l in range(c["num_hidden_layers"]):
             p = f"wav2vec2.encoder.layers.{l}."
-            for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
-                spec += [(p + f"attention.{n}.weight", (H, H), None), (p + f"attention.{n}.bias", (H,), None)]
+            # q | k | v weights side by side in the flat buffers (then their biases): one [3H, H] projection instead of three launches
+            spec += [(p + f"attention.{n}.weight", (H, H), None) for n in ("q_proj", "k_proj", "v_proj")]
+            spec += [(p + f"attention.{n}.bias", (H,), None) for n in ("q_proj", "k_proj", "v_proj")]
+            spec += [(p + "attention.out_proj.weight", (H, H), None), (p + "attention.out_proj.bias", (H,), None)]
             spec += [(p + "layer_norm.weight", (H,), None), (p + "layer_norm.bias", (H,), None),
                      (p + "feed_forward.intermediate_dense.weight", (c["intermediate_size"], H), None),
                      (p + "feed_forward.intermediate_dense.bias", (c["intermediate_size"],), None),
@@ -94,6 +96,17 @@ class Wav2Vec2ForCTC:
         self.P = {n: self.flat_params[o:o + k].view(s) for n, (o, k, s) in slots.items()}
         self.G = {n: self.flat_grads[o:o + k].view(s) for n, (o, k, s) in slots.items()}
         self._kind = {n: kind for n, _, kind in spec}
+        # packed views of the attention input projections: [3H, H] weights / [3H] biases (the slots are contiguous when H % 64 == 0)
+        self.packed_qkv = H % 64 == 0
+        self.Pqkv, self.Gqkv = [], []
+        if self.packed_qkv:
+            for l in range(c["num_hidden_layers"]):
+                ow = slots[f"wav2vec2.encoder.layers.{l}.attention.q_proj.weight"][0]
+                ob = slots[f"wav2vec2.encoder.layers.{l}.attention.q_proj.bias"][0]
+                assert slots[f"wav2vec2.encoder.layers.{l}.attention.v_proj.weight"][0] == ow + 2 * H * H
+                assert slots[f"wav2vec2.encoder.layers.{l}.attention.v_proj.bias"][0] == ob + 2 * H
+                self.Pqkv.append((self.flat_params[ow:ow + 3 * H * H].view(3 * H, H), self.flat_params[ob:ob + 3 * H]))
+                self.Gqkv.append((self.flat_grads[ow:ow + 3 * H * H].view(3 * H, H), self.flat_grads[ob:ob + 3 * H]))
         self.frozen = set()
         self._ctx = None
         self.config = SimpleNamespace(**c)
@@ -214,7 +227,9 @@ class Wav2Vec2ForCTC:
         for l in range(c["num_hidden_layers"]):
             p = f"wav2vec2.encoder.layers.{l}."
             qkv = torch.empty(B, T, 3 * H, device=h.device, dtype=torch.float32)
-            for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+            if self.packed_qkv:
+                ops.linear(h, self.Pqkv[l][0], self.Pqkv[l][1], out=qkv)
+            for j, nm in enumerate(() if self.packed_qkv else ("q_proj", "k_proj", "v_proj")):
                 ops.gemm(h, P[p + f"attention.{nm}.weight"], qkv, trans_b=True, M=B * T, N=H, K=H, lda=H, ldb=H, ldc=3 * H,
                          c_off=j * H, bias=P[p + f"attention.{nm}.bias"])
             S = torch.empty(B, nh, T, T, device=h.device, dtype=torch.float32)
@@ -310,7 +325,11 @@ class Wav2Vec2ForCTC:
                      b_off=0, c_off=H, alpha=sc)
             dh_in = dr1                                              # residual path of the attention block
             M = nb * T
-            for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+            if self.packed_qkv:                                      # the three projections as one [3H, H] product each way
+                ops.gemm(dqkv, h, self.Gqkv[l][0], trans_a=True, M=3 * H, N=H, K=M, lda=3 * H, ldb=H, ldc=H, beta=1.0)
+                ops.colsum(dqkv, self.Gqkv[l][1], beta=1.0)
+                ops.gemm(dqkv, self.Pqkv[l][0], dh_in, M=M, N=H, K=3 * H, lda=3 * H, ldb=H, ldc=H, beta=1.0)
+            for j, nm in enumerate(() if self.packed_qkv else ("q_proj", "k_proj", "v_proj")):
                 # dW += dqkv_j^T h ; db += colsum ; dh += dqkv_j W      (dqkv_j is a strided [M, H] slice, lda = 3H)
                 ops.gemm(dqkv, h, G[p + f"attention.{nm}.weight"], trans_a=True, M=H, N=H, K=M, lda=3 * H, ldb=H, ldc=H, a_off=j * H, beta=1.0)
                 dj = dqkv.view(M, 3, H)[:, j, :].contiguous()
