@@ -109,6 +109,8 @@ class Wav2Vec2ForCTC:
                 self.Gqkv.append((self.flat_grads[ow:ow + 3 * H * H].view(3 * H, H), self.flat_grads[ob:ob + 3 * H]))
         self.frozen = set()
         self._ctx = None
+        self._wq = None
+        self.grouped_wgrad = os.environ.get("DYN_GROUPED_WGRAD", "1") != "0"     # A/B switch: 0 = one launch per weight gradient
         self.config = SimpleNamespace(**c)
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -258,10 +260,19 @@ class Wav2Vec2ForCTC:
         return SimpleNamespace(logits=logits)
 
     # ------------------------------------------------------------------ backward
+    def _wgrad(self, dy, x, dw, db):
+        """dw += dy^T x, db += column sums of dy: queued for the ONE grouped launch that ends the backward (the products of a short
+        utterance are 36 - 144 tiles each: far too few to fill the chip alone), or at once.  Queued operands must stay unmodified."""
+        dy = dy.contiguous()
+        if self._wq is not None and ops.wgrad_groupable(dy, x, dw):
+            self._wq.append(ops.wgrad_desc(dy, x, dw, beta=1.0, colsum=db, colsum_beta=1.0))
+            return
+        ops.linear_wgrad(dy, x, dw, beta=1.0)
+        if db is not None:
+            ops.colsum(dy, db, beta=1.0)
+
     def _lin_bwd(self, dy, x, wname, bname, need_dx=True):
-        ops.linear_wgrad(dy.contiguous(), x, self.G[wname], beta=1.0)
-        if bname is not None:
-            ops.colsum(dy, self.G[bname], beta=1.0)
+        self._wgrad(dy, x, self.G[wname], self.G[bname] if bname is not None else None)
         return ops.linear_dgrad(dy, self.P[wname]) if need_dx else None
 
     def backward(self, grad_logits, n_active=None):
@@ -277,6 +288,15 @@ class Wav2Vec2ForCTC:
                     self.G[n].zero_()
 
     def _backward_body(self, grad_logits, n_active=None):
+        self._wq = [] if self.grouped_wgrad else None
+        try:
+            self._backward_layers(grad_logits, n_active)
+            if self._wq:
+                ops.gemm_grouped(self._wq)      # every linear layer's weight gradient (+ bias sums) of this backward: one launch
+        finally:
+            self._wq = None
+
+    def _backward_layers(self, grad_logits, n_active=None):
         ctx = self._ctx
         if ctx is None:
             raise ops.DynError("backward() without a grad-mode forward")
@@ -323,12 +343,13 @@ class Wav2Vec2ForCTC:
             ops.gemm(dP, qkv, dqkv, M=T, N=D, K=T, lda=T, ldb=3 * H, ldc=3 * H, nb1=nb, nb2=nh, sa=sS, sb=sQ, sc=sQ, b_off=H, c_off=0, alpha=sc)
             ops.gemm(dP, qkv, dqkv, trans_a=True, M=T, N=D, K=T, lda=T, ldb=3 * H, ldc=3 * H, nb1=nb, nb2=nh, sa=sS, sb=sQ, sc=sQ,
                      b_off=0, c_off=H, alpha=sc)
-            dh_in = dr1                                              # residual path of the attention block
             M = nb * T
             if self.packed_qkv:                                      # the three projections as one [3H, H] product each way
-                ops.gemm(dqkv, h, self.Gqkv[l][0], trans_a=True, M=3 * H, N=H, K=M, lda=3 * H, ldb=H, ldc=H, beta=1.0)
-                ops.colsum(dqkv, self.Gqkv[l][1], beta=1.0)
-                ops.gemm(dqkv, self.Pqkv[l][0], dh_in, M=M, N=H, K=3 * H, lda=3 * H, ldb=H, ldc=H, beta=1.0)
+                self._wgrad(dqkv.view(M, 3 * H), h.view(M, H), self.Gqkv[l][0], self.Gqkv[l][1])
+                dh_in = torch.empty_like(dr1)                        # dr1 (residual path) may be a queued operand: not accumulated in place
+                ops.gemm(dqkv, self.Pqkv[l][0], dh_in, M=M, N=H, K=3 * H, lda=3 * H, ldb=H, ldc=H, beta=1.0, c_in=dr1)
+            else:
+                dh_in = dr1.clone() if self._wq is not None else dr1
             for j, nm in enumerate(() if self.packed_qkv else ("q_proj", "k_proj", "v_proj")):
                 # dW += dqkv_j^T h ; db += colsum ; dh += dqkv_j W      (dqkv_j is a strided [M, H] slice, lda = 3H)
                 ops.gemm(dqkv, h, G[p + f"attention.{nm}.weight"], trans_a=True, M=H, N=H, K=M, lda=3 * H, ldb=H, ldc=H, a_off=j * H, beta=1.0)
