@@ -184,6 +184,9 @@ class SCConformerXL:
         self.fused_silu = os.environ.get("DYN_FUSED_SILU", "0") != "0"        # SiLU / SiLU' in the epilogue of the producing GEMM: OFF
         # the backward's launch-bound weight-gradient / bias-sum reductions as one launch at its end (DYN_DEFER_REDUCE=0: one launch each)
         self.defer_reduces = os.environ.get("DYN_DEFER_REDUCE", "1") != "0"
+        # the shared CTC head / re-projection weight gradients (one product per block) through the grouped launch (DYN_STACK_SHARED_WGRAD=0: one launch per use)
+        self.stack_shared_wgrads = os.environ.get("DYN_STACK_SHARED_WGRAD", "1") != "0"
+        self._shared = {}
         self._defer_arena = None
         # by default (A/B on one box, 3 chains: 739 vs 738 audio-s/s, while the GEMM's own rate drops 110 -> 101 TFLOP/s: the
         # activation runs with the MFMA pipe idle, whereas the separate HBM-bound kernels hide under the other chains' GEMMs)
@@ -271,6 +274,22 @@ class SCConformerXL:
                 and ops.wgrad_groupable(dy, x, self.G[wname]):
             self._wq.append(ops.wgrad_desc(dy, x, self.G[wname], alpha=alpha, beta=1.0, colsum=self.G[bname] if bg else None, colsum_beta=1.0))
             bg = False
+        elif wg and self._wq is not None and self.stack_shared_wgrads and wname in ("decoder.ff.weight", "decoder.reproj.weight") \
+                and alpha == 1.0 and ops.wgrad_groupable(dy, x, self.G[wname]):
+            # a weight used once per block (CTC head / re-projection of the self-conditioning): every use writes its OWN slab in the grouped
+            # launch (outputs of one launch must not alias), the slabs are summed into the gradient after it — instead of one small launch
+            # with a read-modify-write of the whole gradient per use
+            sh = self._shared.get(wname)
+            if sh is None:
+                cap = self.config["n_layers"] + 1
+                sh = {"w": torch.empty(cap, *self.G[wname].shape, device=self.device, dtype=torch.float32),
+                      "b": torch.empty(cap, self.G[bname].numel(), device=self.device, dtype=torch.float32) if bg else None, "bname": bname, "k": 0}
+                self._shared[wname] = sh
+            k = sh["k"]
+            sh["k"] = k + 1
+            self._wq.append(ops.wgrad_desc(dy, x, sh["w"][k], alpha=1.0, beta=0.0, colsum=sh["b"][k] if sh["b"] is not None else None, colsum_beta=0.0))
+            if sh["b"] is not None:
+                bg = False
         elif wg:
             ops.linear_wgrad(dy, x, self.G[wname], alpha=alpha, beta=1.0)
         if bg:
@@ -542,11 +561,12 @@ class SCConformerXL:
         finally:
             self._skip_wgrad = False
             self._wq = None
+            self._shared = {}
             self._grad_hidden = None
 
     def _backward_graphed(self, grad_posteriors, n_active):
         G = self._graphs
-        key = (self._ctx_key, tuple(grad_posteriors.shape), n_active, frozenset(self.frozen), self.grouped_wgrad, self.fused_silu, self.defer_reduces)
+        key = (self._ctx_key, tuple(grad_posteriors.shape), n_active, frozenset(self.frozen), self.grouped_wgrad, self.fused_silu, self.defer_reduces, self.stack_shared_wgrads)
         ent = G["bwd"].get(key)
         if ent is None:
             static_g = grad_posteriors.contiguous().clone()
@@ -615,9 +635,7 @@ class SCConformerXL:
                 dp = self._lin_bwd(dh, pz, "decoder.reproj.weight", "decoder.reproj.bias")
                 dzz = ops.softmax_bwd(pz, dp, out=dp)
                 dn = self._lin_bwd(dzz, n, "decoder.ff.weight", "decoder.ff.bias")
-                self._check_not_queued(dh, "the residual-stream gradient (self-conditioning branch)")
-                ops.layernorm_bwd(h0, P["decoder.norm.weight"], mean, rstd, dn, dh, G["decoder.norm.weight"],
-                                  G["decoder.norm.bias"], dx_beta=1.0)
+                dh = self._res_norm_bwd(h0, "decoder.norm.weight", "decoder.norm.bias", mean, rstd, dn, dh)   # dh is a queued operand (re-projection)
             lc = ctx["layers"][l]
             p = f"layers.{l}."
             h0, mean, rstd = lc["norm_out"]
@@ -633,7 +651,13 @@ class SCConformerXL:
         dx = self._sub_bwd(dh, ctx, input_grad)
         if self._wq:
             ops.gemm_grouped(self._wq)      # every block weight gradient (+ bias sums) of this backward: one launch
+            for wname, sh in self._shared.items():      # the per-use slabs of the shared weights, summed in use order
+                k = sh["k"]
+                ops.reduce_partials(sh["w"][:k], self.G[wname], beta=1.0)
+                if sh["b"] is not None:
+                    ops.reduce_partials(sh["b"][:k], self.G[sh["bname"]], beta=1.0)
         self._wq = None
+        self._shared = {}
         if not static:
             self._ctx = None
         return dx

@@ -379,6 +379,16 @@ def axpby(x, y, a=1.0, b=1.0):
     return y
 
 
+def reduce_partials(partial, out, beta=1.0):
+    """out[n] = beta * out[n] + sum_p partial[p, n] (deterministic: p in increasing order per column)."""
+    _cc(partial, "reduce_partials.partial"); _cc(out, "reduce_partials.out")
+    n = out.numel()
+    P = partial.numel() // n
+    assert P * n == partial.numel()
+    check(_L().dyn_reduce_partials(partial.data_ptr(), out.data_ptr(), P, n, beta, _stream()), "dyn_reduce_partials")
+    return out
+
+
 DEFER_ARENA_BYTES = 160 << 20
 
 
