@@ -5,8 +5,13 @@
 //   * GreedyCTCDecoder(...)(out['final_posteriors'][-1].detach().cpu())   (reference lcasr/lib.py:498,559,565;
 //     run_dynamic_eval_full.py:53,100) — here the [T, V+1] posteriors never leave HBM, only the ids do;
 //   * torch.nn.CTCLoss(blank=V, reduction='sum') + its backward            (reference lcasr/lib.py:492,575,579;
-//     reduction='mean' in wav2vec2/lib.py:351).  The gradient follows torch's native formula
-//     (exp(lp) - exp(log(sum alpha*beta) + nll - lp)) * grad_out so results match the reference bit-for-formula.
+//     reduction='mean' in wav2vec2/lib.py:351).  The lattice and the gradient follow torch's CPU kernel
+//     (aten/src/ATen/native/LossCTC.cpp) operation by operation AND rounding by rounding: every exp / log goes through
+//     libm_f32.h (glibc's expf / logf restated bit for bit), every add / subtract is a single fp32 operation in torch's
+//     order, and the per-class log-sum of alpha + beta is accumulated PAIRWISE in descending lattice position exactly as
+//     the CPU loop does (lcab = log(exp(lcab - max) + exp(ab - max)) + max).  On identical log-probs the outputs (nll, alpha,
+//     beta, gradient) are bit-identical to torch._ctc_loss / its backward on the CPU
+//     (tests/test_ops_gpu.py::test_ctc_lattice_is_bitwise_torch_cpu).
 //
 // MI355X mapping: the lattice is latency-bound (T serial steps), so everything that is NOT serial is pulled out
 // of the scan and spread over the chip: the per-step gathers lp[t, label[s]] are pre-gathered by a full-grid kernel
@@ -14,8 +19,11 @@
 // with the previous lattice row in LDS and an 8-deep register prefetch of the slab, and the per-class reduction
 // of alpha*beta is one workgroup per time step.  All reductions run in a fixed order (no float atomics).
 #include "common.h"
+#include "libm_f32.h"
 
 namespace {
+
+namespace glm = dyn::glm;
 
 constexpr int SCAN_T = 1024;  // threads of the serial scan workgroup
 template <int ITEMS> struct ScanCfg { static constexpr int PD = ITEMS >= 8 ? 2 : ITEMS >= 4 ? 4 : 8; };   // slab prefetch distance (time steps): 8 deep
@@ -97,9 +105,10 @@ struct CtcDims {
     int blank;
 };
 
-// Per sample: skip_ok[s] (the s-2 transition is allowed) and next_same[k] (next target index with the same label).
+// Per sample: prev_same[k] (previous target index with the same label, -1 if none) and is_last[k] (no later occurrence): the gradient
+// kernel walks each label's occurrences from the last one down, the order of torch's CPU loop (s = 2S .. 0).
 __global__ __launch_bounds__(1024) void ctc_prep_kernel(const int32_t* __restrict__ targets, const int32_t* __restrict__ tlen,
-                                                        int32_t* __restrict__ next_same, int32_t* __restrict__ is_first,
+                                                        int32_t* __restrict__ prev_same, int32_t* __restrict__ is_last,
                                                         int64_t S_max) {
     // the target row is staged in LDS once: the two scans below are O(S^2) reads of it (S is a few hundred labels per window;
     // from global memory they cost 0.4 ms of pure L2 latency on the chain's critical path)
@@ -114,20 +123,20 @@ __global__ __launch_bounds__(1024) void ctc_prep_kernel(const int32_t* __restric
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int k = w; k < S; k += nw) {
         const int c = tg_s[k];
-        int nx = -1;
+        int pv = -1;
+        for (int j0 = k - 1; j0 >= 0; j0 -= 64) {   // 64 candidates below k per step, nearest first
+            const int j = j0 - lane;
+            const unsigned long long hit = __ballot(j >= 0 && tg_s[j] == c);
+            if (hit) { pv = j0 - (__ffsll((long long)hit) - 1); break; }
+        }
+        int last = 1;
         for (int j0 = k + 1; j0 < S; j0 += 64) {
             const int j = j0 + lane;
-            const unsigned long long hit = __ballot(j < S && tg_s[j] == c);
-            if (hit) { nx = j0 + __ffsll((long long)hit) - 1; break; }
-        }
-        int first = 1;
-        for (int j0 = 0; j0 < k; j0 += 64) {
-            const int j = j0 + lane;
-            if (__ballot(j < k && tg_s[j] == c)) { first = 0; break; }
+            if (__ballot(j < S && tg_s[j] == c)) { last = 0; break; }
         }
         if (lane == 0) {
-            next_same[b * S_max + k] = nx;
-            is_first[b * S_max + k] = first;
+            prev_same[b * S_max + k] = pv;
+            is_last[b * S_max + k] = last;
         }
     }
 }
@@ -145,15 +154,17 @@ __global__ __launch_bounds__(256) void ctc_gather_kernel(const float* __restrict
     for (int s = threadIdx.x; s < L; s += blockDim.x) out[s] = row[(s & 1) ? tg[s >> 1] : d.blank];
 }
 
-__device__ __forceinline__ float lse3(float a, float b, float c) {
-    const float m = fmaxf(a, fmaxf(b, c));
-    if (m == -INFINITY) return -INFINITY;
-    return logf(expf(a - m) + expf(b - m) + expf(c - m)) + m;
+// log(exp(a - m) + exp(b - m) + exp(c - m)) + m with m = max(a, b, c) (0 when all three are -inf), LossCTC.cpp's expression
+__device__ __forceinline__ float lse3(float a, float b, float c, const double* tab) {
+    float m = fmaxf(a, fmaxf(b, c));
+    if (m == -INFINITY) m = 0.f;
+    const float e = __fadd_rn(__fadd_rn(glm::exp_nonpos(__fsub_rn(a, m), tab), glm::exp_nonpos(__fsub_rn(b, m), tab)), glm::exp_nonpos(__fsub_rn(c, m), tab));
+    return __fadd_rn(glm::logf_(e, tab), m);
 }
 
 // Forward scan: alpha[b][t][s]; nll[b].  One workgroup per sample, ITEMS lattice positions per thread.
 template <int ITEMS>
-__device__ __forceinline__ void ctc_alpha_body(float* rows, const float* __restrict__ slab, const int32_t* __restrict__ targets,
+__device__ __forceinline__ void ctc_alpha_body(float* rows, const double* tab, const float* __restrict__ slab, const int32_t* __restrict__ targets,
                                                const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
                                                float* __restrict__ alpha, float* __restrict__ nll, const CtcDims& d) {
     const int SCAN_T = blockDim.x;
@@ -197,7 +208,7 @@ __device__ __forceinline__ void ctc_alpha_body(float* rows, const float* __restr
                         const float a = prev[s];
                         const float bb = s >= 1 ? prev[s - 1] : -INFINITY;
                         const float c = skip[j] ? prev[s - 2] : -INFINITY;
-                        const float v = lse3(a, bb, c) + lpv;
+                        const float v = __fadd_rn(lse3(a, bb, c, tab), lpv);
                         cur[s] = v;
                         al[(int64_t)t * d.L_max + s] = v;
                     }
@@ -209,11 +220,15 @@ __device__ __forceinline__ void ctc_alpha_body(float* rows, const float* __restr
     }
     if (threadIdx.x == 0) {
         float r = INFINITY;
-        if (T > 0) {
+        if (T > 0) {   // LossCTC.cpp: -log(exp(l1 - m) + exp(l2 - m)) - m over the last two positions; an empty target has only position 0
             const float l1 = prev[L - 1];
-            const float l2 = L >= 2 ? prev[L - 2] : -INFINITY;
-            const float m = fmaxf(l1, l2);
-            r = (m == -INFINITY) ? INFINITY : -(logf(expf(l1 - m) + expf(l2 - m)) + m);
+            if (S == 0) r = -l1;
+            else {
+                const float l2 = prev[L - 2];
+                float m = fmaxf(l1, l2);
+                if (m == -INFINITY) m = 0.f;
+                r = -__fadd_rn(glm::logf_(__fadd_rn(glm::exp_nonpos(__fsub_rn(l1, m), tab), glm::exp_nonpos(__fsub_rn(l2, m), tab)), tab), m);
+            }
         }
         nll[b] = r;
     }
@@ -221,7 +236,7 @@ __device__ __forceinline__ void ctc_alpha_body(float* rows, const float* __restr
 
 // Backward scan: beta recursion; overwrites alpha[b][t][s] with alpha + beta.
 template <int ITEMS>
-__device__ __forceinline__ void ctc_beta_body(float* rows, const float* __restrict__ slab, const int32_t* __restrict__ targets,
+__device__ __forceinline__ void ctc_beta_body(float* rows, const double* tab, const float* __restrict__ slab, const int32_t* __restrict__ targets,
                                               const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
                                               float* __restrict__ alpha, const CtcDims& d) {
     const int SCAN_T = blockDim.x;
@@ -268,7 +283,7 @@ __device__ __forceinline__ void ctc_beta_body(float* rows, const float* __restri
                         const float a = prev[s];
                         const float bb = s + 1 < L ? prev[s + 1] : -INFINITY;
                         const float c = skip[j] ? prev[s + 2] : -INFINITY;
-                        const float v = lse3(a, bb, c) + lpv;
+                        const float v = __fadd_rn(lse3(a, bb, c, tab), lpv);
                         cur[s] = v;
                         al[(int64_t)t * d.L_max + s] = v;
                     }
@@ -287,63 +302,69 @@ __global__ __launch_bounds__(1024) void ctc_scan_kernel(const float* __restrict_
                                                          const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
                                                          float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ nll,
                                                          CtcDims d) {
-    extern __shared__ __attribute__((aligned(16))) float rows[];  // 2 * L_max
-    if (blockIdx.y == 0) ctc_alpha_body<ITEMS>(rows, slab, targets, ilen, tlen, alpha, nll, d);
-    else ctc_beta_body<ITEMS>(rows, slab, targets, ilen, tlen, beta, d);
+    extern __shared__ __attribute__((aligned(16))) double scan_lds[];  // the libm tables, then 2 * L_max floats
+    glm::stage_table(scan_lds);   // the bodies barrier before their first lattice step
+    float* rows = (float*)(scan_lds + glm::TABLE_DOUBLES);
+    if (blockIdx.y == 0) ctc_alpha_body<ITEMS>(rows, scan_lds, slab, targets, ilen, tlen, alpha, nll, d);
+    else ctc_beta_body<ITEMS>(rows, scan_lds, slab, targets, ilen, tlen, beta, d);
 }
 
-// grad[t, b, c] = (exp(lp) - exp(lcab[c] + nll - lp)) * g_b, lcab[c] = log sum_{s: label(s) = c} exp(alpha+beta)[t, s].
-// One workgroup per (t, b): all classes get exp(lp) * g, then the classes that occur in the target are corrected:
-// blank by a fixed-order block reduction over the even lattice positions, every other label by the thread that owns
-// its FIRST occurrence walking the next_same chain in increasing s (deterministic).
+// grad[t, b, c] = (exp(lp) - exp(lcab[c] + nll - lp)) * g_b, lcab[c] = log sum_{s: label(s) = c} exp(alpha+beta)[t, s], with the sum taken
+// the way LossCTC.cpp's CPU loop takes it: lattice positions in DESCENDING order, one pairwise log-add per position
+// (lcab = ab if lcab == -inf else log(exp(lcab - max) + exp(ab - max)) + max).  One workgroup per (t, b): alpha + beta of the row goes to LDS,
+// all classes get exp(lp) * g, then the classes that occur in the target are corrected: blank (positions 2S, 2S-2, .., 0) by ONE thread — the
+// chain is serial by construction, S + 1 dependent log-adds, while the 2048 time steps of a window spread over the chip — and every other label by the
+// thread that owns its LAST occurrence walking the prev_same chain.
+__device__ __forceinline__ float log_add_pair(float lcab, float ab, const double* tab) {
+    if (lcab == -INFINITY) return ab;
+    const float mx = lcab < ab ? ab : lcab;   // std::max
+    return __fadd_rn(glm::logf_(__fadd_rn(glm::exp_nonpos(__fsub_rn(lcab, mx), tab), glm::exp_nonpos(__fsub_rn(ab, mx), tab)), tab), mx);
+}
+
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ lp, const float* __restrict__ alpha_,
                                                         const float* __restrict__ beta_,
-                                                        const int32_t* __restrict__ targets, const int32_t* __restrict__ next_same,
-                                                        const int32_t* __restrict__ is_first, const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
+                                                        const int32_t* __restrict__ targets, const int32_t* __restrict__ prev_same,
+                                                        const int32_t* __restrict__ is_last, const int32_t* __restrict__ ilen, const int32_t* __restrict__ tlen,
                                                         const float* __restrict__ nll, float* __restrict__ grad, int64_t g_st,
                                                         int64_t g_sb, float grad_scale, int mean_reduction, CtcDims d) {
-    __shared__ float red[8];
+    extern __shared__ __attribute__((aligned(16))) double grad_lds[];   // the libm tables, then alpha + beta of this row (L floats)
     const int64_t t = blockIdx.x, b = blockIdx.y;
-    const int T = ilen[b], S = tlen[b];
+    const int T = ilen[b], S = tlen[b], L = 2 * S + 1;
     float* gr = grad + t * g_st + b * g_sb;
     if (t >= T) {  // padded frames get zero gradient
         for (int c = threadIdx.x; c < d.C; c += blockDim.x) gr[c] = 0.f;
         return;
     }
+    const double* tab = grad_lds;
+    float* ab = (float*)(grad_lds + glm::TABLE_DOUBLES);
+    glm::stage_table(grad_lds);
     float g = grad_scale;
-    if (mean_reduction) g = grad_scale / ((float)(S > 0 ? S : 1) * (float)d.B);
+    if (mean_reduction) g = (grad_scale / (float)d.B) / (float)(S > 0 ? S : 1);   // MeanBackward, then DivBackward by clamp_min(target_len, 1)
     const float* row = lp + t * d.lp_st + b * d.lp_sb;
     const float* ar = alpha_ + (b * d.T_max + t) * d.L_max;
     const float* br = beta_ + (b * d.T_max + t) * d.L_max;
     const int32_t* tg = targets + b * d.S_max;
-    const int32_t* nx = next_same + b * d.S_max;
+    const int32_t* pv = prev_same + b * d.S_max;
     const float nl = nll[b];
-    for (int c = threadIdx.x; c < d.C; c += blockDim.x) gr[c] = expf(row[c]) * g;
-    // blank: positions 0, 2, ..., 2S
-    float m = -INFINITY;
-    for (int k = threadIdx.x; k <= S; k += blockDim.x) m = fmaxf(m, ar[2 * k] + br[2 * k]);
-    m = dyn::block_max(m, red);
-    float sum = 0.f;
-    if (m != -INFINITY)
-        for (int k = threadIdx.x; k <= S; k += blockDim.x) sum += expf(ar[2 * k] + br[2 * k] - m);
-    sum = dyn::block_sum(sum, red);  // also orders the exp(lp)*g stores before the corrections below
+    for (int s = threadIdx.x; s < L; s += blockDim.x) ab[s] = __fadd_rn(ar[s], br[s]);
+    __syncthreads();
+    // res = -inf for a class outside the target: (exp(lp) - exp(-inf)) * g
+    for (int c = threadIdx.x; c < d.C; c += blockDim.x) gr[c] = __fmul_rn(glm::expf_(row[c], tab), g);
+    __syncthreads();   // orders the stores above before the corrections below (same workgroup, same addresses)
     if (threadIdx.x == 0) {
+        float lcab = -INFINITY;
+        for (int k = S; k >= 0; --k) lcab = log_add_pair(lcab, ab[2 * k], tab);
         const float lpb = row[d.blank];
-        const float lcab = (m == -INFINITY) ? -INFINITY : logf(sum) + m;
-        gr[d.blank] = (expf(lpb) - expf(lcab + nl - lpb)) * g;
+        gr[d.blank] = __fmul_rn(__fsub_rn(glm::expf_(lpb, tab), glm::expf_(__fsub_rn(__fadd_rn(lcab, nl), lpb), tab)), g);
     }
-    // labels: thread k handles target index k if it is the first occurrence of its label
-    for (int k = threadIdx.x; k < S; k += blockDim.x) {
-        if (!is_first[b * d.S_max + k]) continue;
+    // labels: a thread of waves 1 .. 3 handles target index k if it is the last occurrence of its label (wave 0 is busy with the blank chain)
+    for (int k = (int)threadIdx.x - 64; k < S; k += (int)blockDim.x - 64) {
+        if (k < 0 || !is_last[b * d.S_max + k]) continue;
         const int c = tg[k];
-        float mm = -INFINITY;
-        for (int j = k; j >= 0; j = nx[j]) mm = fmaxf(mm, ar[2 * j + 1] + br[2 * j + 1]);
-        float ss = 0.f;
-        if (mm != -INFINITY)
-            for (int j = k; j >= 0; j = nx[j]) ss += expf(ar[2 * j + 1] + br[2 * j + 1] - mm);
-        const float lcab = (mm == -INFINITY) ? -INFINITY : logf(ss) + mm;
+        float lcab = -INFINITY;
+        for (int j = k; j >= 0; j = pv[j]) lcab = log_add_pair(lcab, ab[2 * j + 1], tab);
         const float lpc = row[c];
-        gr[c] = (expf(lpc) - expf(lcab + nl - lpc)) * g;
+        gr[c] = __fmul_rn(__fsub_rn(glm::expf_(lpc, tab), glm::expf_(__fsub_rn(__fadd_rn(lcab, nl), lpc), tab)), g);
     }
 }
 
@@ -361,7 +382,7 @@ __global__ void ctc_loss_reduce_kernel(const float* __restrict__ nll, const int3
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct CtcWs {
-    float* slab; float* alpha; float* beta; float* nll; int32_t* next_same; int32_t* is_first;
+    float* slab; float* alpha; float* beta; float* nll; int32_t* prev_same; int32_t* is_last;
     int64_t total;
 };
 
@@ -374,8 +395,8 @@ CtcWs carve(void* ws, int64_t T, int64_t B, int64_t S_max) {
     w.alpha = (float*)(p + off); off += align_up(B * T * L * 4, 256);
     w.beta = (float*)(p + off); off += align_up(B * T * L * 4, 256);
     w.nll = (float*)(p + off); off += align_up(B * 4, 256);
-    w.next_same = (int32_t*)(p + off); off += align_up((B * S_max + 1) * 4, 256);
-    w.is_first = (int32_t*)(p + off); off += align_up((B * S_max + 1) * 4, 256);
+    w.prev_same = (int32_t*)(p + off); off += align_up((B * S_max + 1) * 4, 256);
+    w.is_last = (int32_t*)(p + off); off += align_up((B * S_max + 1) * 4, 256);
     w.total = off;
     return w;
 }
@@ -410,6 +431,41 @@ extern "C" int64_t dyn_ctc_loss_workspace_bytes(int64_t T, int64_t B, int64_t S_
     return carve(nullptr, T, B, S_max > 0 ? S_max : 1).total;
 }
 
+extern "C" int dyn_ctc_loss_workspace_layout(int64_t T, int64_t B, int64_t S_max, int64_t* offsets4, int64_t* row_len) {
+    DYN_REQUIRE(offsets4 && row_len && T > 0 && B > 0 && S_max >= 0, DYN_E_ARG, "dyn_ctc_loss_workspace_layout: bad arguments");
+    const int64_t Sm = S_max > 0 ? S_max : 1;
+    const CtcWs w = carve(nullptr, T, B, Sm);
+    offsets4[0] = (char*)w.slab - (char*)nullptr;
+    offsets4[1] = (char*)w.alpha - (char*)nullptr;
+    offsets4[2] = (char*)w.beta - (char*)nullptr;
+    offsets4[3] = (char*)w.nll - (char*)nullptr;
+    *row_len = 2 * Sm + 1;
+    return DYN_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void libm_f32_kernel(const float* __restrict__ x, int64_t n, float* y_exp, float* y_log, float* y_np) {
+    __shared__ double tab[glm::TABLE_DOUBLES];
+    glm::stage_table(tab);
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        if (y_exp) y_exp[i] = glm::expf_(v, tab);
+        if (y_log) y_log[i] = glm::logf_(v, tab);
+        if (y_np) y_np[i] = glm::exp_nonpos(v, tab);
+    }
+}
+}  // namespace
+
+extern "C" int dyn_libm_f32(const float* x, int64_t n, float* y_exp, float* y_log, float* y_exp_nonpos, void* stream) {
+    DYN_REQUIRE(x && n >= 0, DYN_E_ARG, "dyn_libm_f32: bad arguments");
+    if (n == 0) return DYN_OK;
+    int64_t g = dyn::cdiv(n, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(libm_f32_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, n, y_exp, y_log, y_exp_nonpos);
+    return dyn::check_launch("dyn_libm_f32");
+}
+
 extern "C" int dyn_ctc_loss(const float* log_probs, int64_t T, int64_t B, int64_t C, int64_t lp_stride_t, int64_t lp_stride_b,
                             const int32_t* targets, int64_t S_max, const int32_t* input_lengths, const int32_t* target_lengths,
                             int32_t blank, int32_t reduction, float grad_scale, float* loss, float* nll_per_sample,
@@ -428,13 +484,13 @@ extern "C" int dyn_ctc_loss(const float* log_probs, int64_t T, int64_t B, int64_
     CtcDims d;
     d.T_max = T; d.B = B; d.C = C; d.lp_st = lp_stride_t; d.lp_sb = lp_stride_b; d.S_max = Sm; d.L_max = L; d.blank = blank;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(ctc_prep_kernel, dim3((unsigned)B), dim3(1024), (size_t)Sm * sizeof(int32_t), st, targets, target_lengths, w.next_same, w.is_first, Sm);
+    hipLaunchKernelGGL(ctc_prep_kernel, dim3((unsigned)B), dim3(1024), (size_t)Sm * sizeof(int32_t), st, targets, target_lengths, w.prev_same, w.is_last, Sm);
     hipLaunchKernelGGL(ctc_gather_kernel, dim3((unsigned)T, (unsigned)B), dim3(256), 0, st, log_probs, targets, input_lengths,
                        target_lengths, w.slab, d);
     int threads = (int)((L + 63) / 64 * 64);
     if (threads > SCAN_T) threads = SCAN_T;
     const int items = (int)dyn::cdiv(L, threads);
-    const size_t shm = (size_t)2 * L * sizeof(float);
+    const size_t shm = (size_t)2 * L * sizeof(float) + glm::TABLE_DOUBLES * sizeof(double);
     const dim3 sgrid((unsigned)B, grad ? 2u : 1u);
 #define GO_S(I) hipLaunchKernelGGL((ctc_scan_kernel<I>), sgrid, dim3(threads), shm, st, w.slab, targets, input_lengths, target_lengths, w.alpha, w.beta, w.nll, d)
     if (items <= 1) GO_S(1); else if (items <= 2) GO_S(2); else if (items <= 4) GO_S(4); else GO_S(8);
@@ -444,8 +500,8 @@ extern "C" int dyn_ctc_loss(const float* log_probs, int64_t T, int64_t B, int64_
         DYN_REQUIRE(e == hipSuccess, DYN_E_LAUNCH, "dyn_ctc_loss: copy of per-sample nll failed");
     }
     if (grad) {
-        hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)T, (unsigned)B), dim3(256), 0, st, log_probs, w.alpha, w.beta, targets,
-                           w.next_same, w.is_first, input_lengths, target_lengths, w.nll, grad, g_stride_t, g_stride_b, grad_scale,
+        hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)T, (unsigned)B), dim3(256), (size_t)L * sizeof(float) + glm::TABLE_DOUBLES * sizeof(double), st, log_probs, w.alpha, w.beta, targets,
+                           w.prev_same, w.is_last, input_lengths, target_lengths, w.nll, grad, g_stride_t, g_stride_b, grad_scale,
                            (int)reduction, d);
     }
 #undef GO_S

@@ -806,6 +806,30 @@ def ctc_loss(log_probs, targets, input_lengths, target_lengths, blank, reduction
     return loss, nll, grad
 
 
+def ctc_lattice(T, B, S_max, device):
+    """Views of the lattice the last ops.ctc_loss call of this (device, stream) left in the workspace:
+    (alpha [B, T, L], beta [B, T, L], nll [B]) with L = 2 * max(S_max, 1) + 1; beta is only written when a gradient was asked for."""
+    import ctypes
+    off = (ctypes.c_int64 * 4)()
+    L = ctypes.c_int64()
+    check(_L().dyn_ctc_loss_workspace_layout(T, B, S_max, ctypes.cast(off, ctypes.c_void_p), ctypes.cast(ctypes.byref(L), ctypes.c_void_p)),
+          "dyn_ctc_loss_workspace_layout")
+    ws = workspace(device)
+    n = B * T * L.value * 4
+    alpha = ws[off[1]:off[1] + n].view(F32).view(B, T, L.value)
+    beta = ws[off[2]:off[2] + n].view(F32).view(B, T, L.value)
+    nll = ws[off[3]:off[3] + 4 * B].view(F32)
+    return alpha, beta, nll
+
+
+def libm_f32(x):
+    """(expf(x), logf(x), the lattice's branch-free expf for x <= 0) from the device build of csrc/libm_f32.h."""
+    _cc(x, "libm_f32.x")
+    e, l, n = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    check(_L().dyn_libm_f32(x.data_ptr(), x.numel(), e.data_ptr(), l.data_ptr(), n.data_ptr(), _stream()), "dyn_libm_f32")
+    return e, l, n
+
+
 # ----------------------------------------------------------------------------------------------- optimiser / stitch
 def madgrad_step(p, g, s, nu, x0, lr, momentum, weight_decay, eps, step):
     for t, n in ((p, "p"), (g, "g"), (s, "s"), (nu, "nu"), (x0, "x0")):

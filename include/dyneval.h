@@ -368,10 +368,19 @@ int dyn_decoder_steps(const dyn_decoder_desc* d, int32_t t0, int32_t n_steps, in
  * wav2vec2/lib.py:351,434): log_probs[t, b, c] at t*lp_stride_t + b*lp_stride_b + c; targets [B, S_max] int32;
  * reduction 0 = 'sum' (loss = sum_b nll_b, grad scaled by grad_scale), 1 = 'mean' (nll_b / max(S_b,1), mean over B).
  * grad (optional) gets torch's native gradient w.r.t. log_probs, same addressing with g_stride_*.
+ * Rounding contract (r04): every exp / log of the lattice and the gradient is glibc's expf / logf bit for bit (csrc/libm_f32.h), every
+ * add / subtract one fp32 operation in the order of aten/native/LossCTC.cpp's CPU kernel, the per-class log-sum pairwise in descending
+ * lattice position: on identical log_probs the nll, alpha, beta and gradient are bit-identical to torch's CPU CTC.
+ * dyn_ctc_loss_workspace_layout: byte offsets of {gathered slab, alpha, beta, nll} inside the workspace and the lattice row length
+ * L = 2 * max(S_max, 1) + 1 (alpha / beta are [B, T, L] fp32) — lets a caller or a test read the lattice a dyn_ctc_loss call left behind.
+ * dyn_libm_f32: y_exp[i] = expf(x[i]), y_log[i] = logf(x[i]), y_exp_nonpos[i] = the branch-free x <= 0 variant the lattice uses
+ * (any output may be NULL): the device build of csrc/libm_f32.h, for comparison with the host's libm.
  * ------------------------------------------------------------------------------------------------ */
 int dyn_ctc_greedy(const float* log_probs, int64_t B, int64_t T, int64_t C, int64_t ld, int32_t blank, int32_t* argmax_ids,
                    int32_t* out_ids, int32_t* out_len, void* stream);
 int64_t dyn_ctc_loss_workspace_bytes(int64_t T, int64_t B, int64_t S_max);
+int dyn_ctc_loss_workspace_layout(int64_t T, int64_t B, int64_t S_max, int64_t* offsets4, int64_t* row_len);
+int dyn_libm_f32(const float* x, int64_t n, float* y_exp, float* y_log, float* y_exp_nonpos, void* stream);
 int dyn_ctc_loss(const float* log_probs, int64_t T, int64_t B, int64_t C, int64_t lp_stride_t, int64_t lp_stride_b,
                  const int32_t* targets, int64_t S_max, const int32_t* input_lengths, const int32_t* target_lengths,
                  int32_t blank, int32_t reduction, float grad_scale, float* loss, float* nll_per_sample, float* grad,

@@ -265,6 +265,83 @@ def test_ctc_loss_and_grad(cuda, T, C, S, reduction):
     _close(grad, lpr.grad, scale * max(1.3e-3, 4e-6 * T), "ctc grad")
 
 
+def _bits(t):
+    return t.detach().cpu().contiguous().view(torch.int32)
+
+
+def test_device_libm_matches_the_host_libm(cuda):
+    """csrc/libm_f32.h on the device against the expf / logf of THIS machine's libm.so.6 — the functions torch's CPU CTC kernel calls
+    (aten/native/LossCTC.cpp: std::exp / std::log on float).  Bit for bit, NaN payloads aside."""
+    import ctypes
+    import numpy as np
+    from dynamic_asr_eval_amd import ops
+    libm = ctypes.CDLL("libm.so.6")
+    libm.expf.restype = ctypes.c_float; libm.expf.argtypes = [ctypes.c_float]
+    libm.logf.restype = ctypes.c_float; libm.logf.argtypes = [ctypes.c_float]
+    g = _g(271)
+    n = 60000
+    xs = torch.cat([
+        -torch.rand(n, generator=g) * 110.0,                                  # the lattice's range, into the underflow band
+        (torch.rand(n, generator=g) - 0.5) * 180.0,
+        torch.randn(n, generator=g).exp() * 3.0,                              # logf arguments around 1 .. 3 (sums of up to three exps)
+        torch.rand(n, generator=g) * 2.0 + 0.5,
+        (torch.randint(0, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int64).int()).view(torch.float32),   # any positive bit pattern
+        torch.tensor([0.0, -0.0, 1.0, 2.0, 3.0, -87.3, -88.0, -103.0, -103.97, -103.98, -104.0, 88.7, 88.8, 1e-45, 1e-40,
+                      float("inf"), float("-inf"), float("nan"), -1.0, 0.5, 1.0000001, 0.99999994]),
+    ])
+    e, l, enp = (t.cpu().numpy() for t in ops.libm_f32(xs.to(cuda)))
+    xn = xs.numpy()
+    he = np.array([libm.expf(float(v)) for v in xn], dtype=np.float32)
+    hl = np.array([libm.logf(float(v)) for v in xn], dtype=np.float32)
+
+    def same(a, b):
+        return (a.view(np.int32) == b.view(np.int32)) | (np.isnan(a) & np.isnan(b))
+    assert same(e, he).all(), f"expf: {(~same(e, he)).sum()} of {len(xn)} differ, first at x = {xn[~same(e, he)][:5]}"
+    assert same(l, hl).all(), f"logf: {(~same(l, hl)).sum()} of {len(xn)} differ, first at x = {xn[~same(l, hl)][:5]}"
+    neg = (xn <= 0) & ~np.isnan(xn)
+    assert same(enp[neg], he[neg]).all(), "the branch-free x <= 0 expf differs from libm"
+
+
+# (T, C, S per sample, reduction): the BASELINE config-2 shape first (T' = 2048 encoder frames, V + 1 = 4096, a speech-like 450 labels),
+# then the wider scan kernels <2>, <4>, an empty target and a short second sample.
+@pytest.mark.parametrize("T,C,S,reduction", [(2048, 4096, (450, 431), "sum"), (2048, 129, (1030, 600), "sum"), (700, 33, (340, 0), "mean"),
+                                            (2300, 129, (1100, 1024), "mean"), (300, 40, (0, 0), "sum")])
+def test_ctc_lattice_is_bitwise_torch_cpu(cuda, T, C, S, reduction):
+    """VERDICT r03 item 1: IDENTICAL log-probs into dyn_ctc_loss and into torch's CPU CTC (torch._ctc_loss returns (nll, log_alpha));
+    the lattice, the nll and the gradient w.r.t. the log-probs must agree BIT FOR BIT — same libm roundings, same operation order."""
+    from dynamic_asr_eval_amd import ops
+    B = 2
+    g = _g(4242 + T + C)
+    logits = torch.randn(B, T, C, generator=g) * 3.0
+    logits[:, :, C - 1] += 4.0   # blank-heavy and peaky like a trained model: |alpha| grows to the thousands
+    lp = F.log_softmax(logits, -1)
+    Sm = max(max(S), 1)
+    tgt = torch.randint(0, C - 1, (B, Sm), generator=g)
+    for b in range(B):           # repeated labels (no skip transition), a run of three, repeats far apart (prev_same chains)
+        if S[b] >= 8:
+            tgt[b, 1] = tgt[b, 0]
+            tgt[b, 5] = tgt[b, 4] = tgt[b, 3]
+            tgt[b, S[b] - 1] = tgt[b, 0]
+    tl = torch.tensor(list(S)); il = torch.tensor([T, T - 5])
+    nll_ref, alpha_ref = torch._ctc_loss(lp.transpose(0, 1), tgt, il.tolist(), tl.tolist(), C - 1, False)
+    lpr = lp.clone().requires_grad_()
+    scale = 1.0 / (T * B)
+    (F.ctc_loss(lpr.transpose(0, 1), tgt, il, tl, blank=C - 1, reduction=reduction) * scale).backward()
+    loss, nll, grad = ops.ctc_loss(lp.to(cuda), tgt.int().to(cuda), il.int().to(cuda), tl.int().to(cuda), C - 1,
+                                   reduction=reduction, grad_scale=scale)
+    alpha, beta, _ = ops.ctc_lattice(T, B, Sm, cuda)
+    alpha = alpha.cpu()
+    assert torch.equal(_bits(nll), _bits(nll_ref)), (nll.cpu().tolist(), nll_ref.tolist())
+    cells = same_cells = 0
+    for b in range(B):
+        Tb, Lb = int(il[b]), 2 * int(tl[b]) + 1
+        a, r = alpha[b, :Tb, :Lb], alpha_ref[b, :Tb, :Lb]
+        cells += a.numel(); same_cells += int((_bits(a) == _bits(r)).sum())
+    assert same_cells == cells, f"alpha: {cells - same_cells} of {cells} cells differ from torch's CPU lattice"
+    gb, gr = _bits(grad), _bits(lpr.grad)
+    assert torch.equal(gb, gr), f"gradient: {(gb != gr).sum().item()} of {gb.numel()} elements differ, max |d| {(grad.cpu() - lpr.grad).abs().max().item():.3e}"
+
+
 def test_optimizers_match_torch(cuda):
     from dynamic_asr_eval_amd import ops
     import sys, os
