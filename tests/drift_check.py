@@ -13,7 +13,13 @@ after ONE step at lr 9e-5).
 Per 256-row band of the stitched output (one band = the 2048-frame stride): the online curve shows the drift after k adapt
 steps (band b >= 8 is covered by windows b-7 ... only), the offline curve the final pass with the fully adapted weights.
 
-  python tests/drift_check.py [--windows 8] [--fp64 1] [--grad_diag 1] [--out profiles/r03_drift.json]
+  python tests/drift_check.py [--windows 8] [--fp64 1] [--grad_diag 1] [--spec_seed 77] [--mask_seed 9] [--out profiles/r04_drift_s77.json]
+
+r04 — the full-length record of BASELINE config 2: `--windows 169 --fp64 0 --grad_diag 0 --budget_s 1000` runs ALL
+169 windows of a 1 h recording (360 000 frames) through both sides; `--budget_s` first times the oracle on two windows and, if the
+full recording would not fit the budget on this box's host cores, shortens the recording to the number of carried steps that does
+(recorded as `windows`).  Besides the per-band curves the record holds the argmax mismatches with the ORACLE's own top-2 margin at
+each of them and the edit distance between the two final transcripts (greedy CTC ids of the stitched output).
 """
 import argparse
 import json
@@ -40,6 +46,59 @@ def bands(a, b):
     return ([float(f"{d[k * BAND:(k + 1) * BAND].max():.3e}") for k in range(nb)], [int(bad[k * BAND:(k + 1) * BAND].sum()) for k in range(nb)])
 
 
+def mismatch_margins(a, b):
+    """Rows where the argmax differs, with the oracle's (b's) margin between its two largest log-probs there."""
+    n = min(a.shape[0], b.shape[0])
+    rows = np.nonzero(a[:n].argmax(-1) != b[:n].argmax(-1))[0]
+    out = []
+    for r in rows[:200]:
+        top = np.sort(b[r])[-2:]
+        out.append({"row": int(r), "oracle_margin": float(f"{top[1] - top[0]:.3e}"), "hip_id": int(a[r].argmax()), "oracle_id": int(b[r].argmax())})
+    return out
+
+
+def edit_distance(x, y):
+    prev = list(range(len(y) + 1))
+    for i, xi in enumerate(x, 1):
+        cur = [i]
+        for j, yj in enumerate(y, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (xi != yj)))
+        prev = cur
+    return prev[-1]
+
+
+def greedy_ids(lp, blank):
+    ids, prev = [], None
+    for i in lp.argmax(-1).tolist():
+        if i != blank and i != prev:
+            ids.append(i)
+        prev = i
+    return ids
+
+
+def with_progress(fn, timings, total, label):
+    """Runs fn() in a worker thread and prints a progress line every 45 s (gpurun takes 7 silent minutes for a hang)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["out"] = fn()
+        except BaseException as e:   # noqa: BLE001 — re-raised in the caller's thread
+            box["err"] = e
+    th = threading.Thread(target=run)
+    th.start()
+    t0 = time.time()
+    while th.is_alive():
+        th.join(45.0)
+        if th.is_alive():
+            print(f"[drift] {label}: {len(timings.get('adapt', []))}/{total} adapt steps, {len(timings.get('final', []))} final-pass windows, "
+                  f"{time.time() - t0:.0f} s", flush=True)
+    if "err" in box:
+        raise box["err"]
+    return box["out"]
+
+
 def make_args(masks, online, lr):
     ns = argparse.Namespace()
     ns.config = {'model': {'subsampling_factor': 8}, 'audio_chunking': {'size': SEQ, 'overlap': 0}, 'training': {'max_seq_len': 0}}
@@ -54,7 +113,14 @@ def main():
     ap.add_argument("--grad_diag", type=int, default=1)
     ap.add_argument("--lr", type=float, default=9e-5)
     ap.add_argument("--threads", type=int, default=16)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_drift.json"))
+    ap.add_argument("--spec_seed", type=int, default=77)
+    ap.add_argument("--mask_seed", type=int, default=9)
+    ap.add_argument("--blank_bias", type=float, default=1.34)
+    ap.add_argument("--label_tokens", type=int, default=0, help="> 0: tokenizer.encode returns this many fixed seeded ids per window on BOTH sides "
+                    "(bench.py's SubstituteLabelTokenizer): a seeded model's own labels collapse to blank after a few steps, this keeps every "
+                    "carried step on a speech-like lattice (|alpha| in the thousands)")
+    ap.add_argument("--budget_s", type=float, default=0.0, help="> 0: shorten the recording so that the fp32 oracle fits this many seconds")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_drift.json"))
     a = ap.parse_args()
     from oracle import dynamic_eval_ref as R
     from oracle.conformer_ref import SCConformerXLRef
@@ -65,15 +131,35 @@ def main():
     from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
     torch.set_num_threads(a.threads)
     dev = torch.device("cuda:0")
-    ref = SCConformerXLRef(vocab_size=VOCAB, seed=0, blank_bias=1.34)
+    ref = SCConformerXLRef(vocab_size=VOCAB, seed=0, blank_bias=a.blank_bias)
     hip = SCConformerXL(vocab_size=VOCAB, device=dev)
     hip.load_state_dict(ref.state_dict())
     tok = SyntheticTokenizer(VOCAB)
-    spec = synthetic_spec(SEQ + (a.windows - 1) * (SEQ - OVL), seed=77)
+    if a.label_tokens > 0:
+        from bench import SubstituteLabelTokenizer
+        tok = SubstituteLabelTokenizer(tok, a.label_tokens)
+    res = {"what": __doc__.split("\n\n")[0], "lr": a.lr, "band_rows": BAND, "spec_seed": a.spec_seed, "mask_seed": a.mask_seed,
+           "host_threads": a.threads, "requested_windows": a.windows,
+           "label_tokens": a.label_tokens}
+    if a.budget_s > 0:   # two oracle windows (adapt step + final-pass window each) give this box's per-window cost
+        probe = synthetic_spec(SEQ + (SEQ - OVL), seed=a.spec_seed + 1)
+        _, pk = R.prepare_chunks(probe, SEQ, OVL)
+        gm = torch.Generator().manual_seed(1)
+        tm = {}
+        R.dynamic_eval_ref(ref, probe, SEQ, OVL, tok, MADGRAD_REF, {'lr': a.lr}, {}, fixed_masks={k: (R.draw_masks(6, 34, 80, gm), ([], [])) for k in pk},
+                           max_windows=2, timings=tm)
+        per = min(tm['adapt']) + min(tm['final'])
+        fit = int(a.budget_s / (per * 1.05))
+        res["oracle_probe_s_per_window"] = round(per, 2)
+        print(f"[drift] oracle probe: {per:.2f} s per window (adapt step + final-pass window) -> {fit} windows fit {a.budget_s:.0f} s", flush=True)
+        a.windows = max(2, min(a.windows, fit))
+    # 169 windows = the 360 000-frame recording of BASELINE config 2 (prepare_chunks: 168 full windows + the 15 936-frame tail)
+    n_frames = 360000 if a.windows >= 169 else SEQ + (a.windows - 1) * (SEQ - OVL)
+    spec = synthetic_spec(n_frames, seed=a.spec_seed)
     _, keys = R.prepare_chunks(spec, SEQ, OVL)
-    g = torch.Generator().manual_seed(9)
+    g = torch.Generator().manual_seed(a.mask_seed)
     masks = {k: (R.draw_masks(6, 34, 80, g), ([], [])) for k in keys}
-    res = {"what": __doc__.split("\n\n")[0], "windows": len(keys), "keys": keys, "lr": a.lr, "band_rows": BAND}
+    res.update({"windows": len(keys), "frames": n_frames, "keys": keys})
 
     t0 = time.time()
     hip_off = lib.dynamic_eval(make_args(masks, False, a.lr), hip, spec, SEQ, OVL, tok, use_tqdm=False)
@@ -81,14 +167,18 @@ def main():
     res["hip_seconds"] = round(time.time() - t0, 2)
     print(f"[drift] HIP done in {res['hip_seconds']} s", flush=True)
     t0 = time.time()
-    f32_off, f32_on, p32 = R.dynamic_eval_ref(ref, spec, SEQ, OVL, tok, MADGRAD_REF, {'lr': a.lr}, {}, fixed_masks=masks, also_online=True,
-                                              return_params=True)
+    tm32 = {}
+    f32_off, f32_on, p32 = with_progress(lambda: R.dynamic_eval_ref(ref, spec, SEQ, OVL, tok, MADGRAD_REF, {'lr': a.lr}, {}, fixed_masks=masks,
+                                                                    also_online=True, return_params=True, timings=tm32), tm32, len(keys), "fp32 oracle")
     res["oracle_f32_seconds"] = round(time.time() - t0, 1)
     print(f"[drift] fp32 oracle done in {res['oracle_f32_seconds']} s", flush=True)
     for name, x, y in (("offline_hip_vs_f32", hip_off, f32_off), ("online_hip_vs_f32", hip_on, f32_on)):
         d, bad = bands(x, y)
-        res[name] = {"max_abs_dlogp_per_band": d, "argmax_mismatch_per_band": bad, "max": max(d), "mismatches": sum(bad), "rows": int(min(x.shape[0], y.shape[0]))}
-        print(f"[drift] {name}: max {max(d):.3e}, mismatches {sum(bad)}; per band {d}", flush=True)
+        hyp, want = greedy_ids(x, VOCAB), greedy_ids(y, VOCAB)
+        res[name] = {"max_abs_dlogp_per_band": d, "argmax_mismatch_per_band": bad, "max": max(d), "mismatches": sum(bad), "rows": int(min(x.shape[0], y.shape[0])),
+                     "bands_over_1e-3": int(sum(v > 1e-3 for v in d)), "mismatch_rows": mismatch_margins(x, y),
+                     "transcript": {"hip_tokens": len(hyp), "oracle_tokens": len(want), "edit_distance": edit_distance(hyp, want)}}
+        print(f"[drift] {name}: max {max(d):.3e}, mismatches {sum(bad)}, transcript edits {res[name]['transcript']}; per band {d}", flush=True)
     if a.fp64:
         t0 = time.time()
         ref64 = SCConformerXLRef(vocab_size=VOCAB, seed=0, blank_bias=1.34).double()

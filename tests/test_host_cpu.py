@@ -390,3 +390,42 @@ def test_fused_attention_grad_switch_is_validated_where_it_is_set():
     for bad in ("auto", "", "-1", "1.5"):
         with pytest.raises(ValueError):
             _parse_fused_attn_grad(bad)
+
+
+def test_libm_restatement_is_bitwise_the_system_libm(tmp_path):
+    """csrc/libm_f32.h (the expf / logf the CTC lattice kernels use, so that they round like torch's CPU CTC) compiled for the HOST against
+    this machine's libm.so.6 — every 251st float bit pattern (17 M inputs incl. negatives, subnormals, inf, nan; the full 2^32 sweep was run
+    once in the build container: 0 mismatches) plus the 2^16 patterns around each special boundary."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    hdr = os.path.join(ROOT, "dynamic-asr-eval_amd", "csrc", "libm_f32.h")
+    src = tmp_path / "libm_check.cpp"
+    src.write_text('#include "%s"\n' % hdr + r'''
+#include <stdio.h>
+#include <math.h>
+using namespace dyn::glm;
+static long check(uint32_t u, const double* tab) {
+    float x = u2f(u); long bad = 0;
+    float a = expf(x), b = expf_(x, tab), c = logf(x), d = logf_(x, tab);
+    if (f2u(a) != f2u(b) && !(a != a && b != b)) bad++;
+    if (f2u(c) != f2u(d) && !(c != c && d != d)) bad++;
+    if (x <= 0 && !(x != x)) { float e = exp_nonpos(x, tab); if (f2u(a) != f2u(e)) bad++; }
+    return bad;
+}
+int main() {
+    double tab[TABLE_DOUBLES]; fill_table_host(tab);
+    long bad = 0, n = 0;
+    for (uint64_t u = 0; u < (1ull << 32); u += 251) { bad += check((uint32_t)u, tab); n++; }
+    const uint32_t around[] = {0x00000000u, 0x00800000u, 0x3f800000u, 0x42b00000u, 0x42b17218u, 0x7f800000u, 0x80000000u, 0xc2aeac50u,
+                               0xc2cff1b4u, 0xc2ce8ed0u, 0xff800000u, 0x3f330000u};
+    for (uint32_t c : around) for (int64_t k = -32768; k < 32768; ++k) { bad += check((uint32_t)((int64_t)c + k), tab); n++; }
+    printf("%ld inputs %ld mismatches\n", n, bad);
+    return bad != 0;
+}
+''')
+    exe = tmp_path / "libm_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", str(src), "-o", str(exe), "-lm"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
