@@ -105,3 +105,22 @@ def params_digest(params):
     """What is stored of an updated parameter list: every 23rd element of the flattened list + its float64 sum and absolute sum."""
     flat = torch.cat([p.detach().reshape(-1) for p in params])
     return flat[::23].numpy().copy(), [float(flat.double().sum()), float(flat.double().abs().sum())]
+
+
+# ---- BASELINE config 5: the outer loop of lcasr/run_cross_dataset_eval.py on toy recordings
+CROSS_CASES = (("same_overlap", (900, 700, 1100), (800, 600), dict(optim_lr=4e-6, epochs=1, seq_len=512, overlap=256, adapt_overlap=None,
+                                                                       repeats=1, awmc=False, beamsearch=False, save_path='')),
+               ("adapt_overlap", (1000, 650), (700, 900, 520), dict(optim_lr=3e-6, epochs=2, seq_len=512, overlap=256, adapt_overlap=384,
+                                                                      repeats=1, awmc=False, beamsearch=False, save_path='')))
+
+
+def toy_records(lens, seed):
+    """Records with the harness contract {'process_fn': rec -> (spec [1, 80, T], gold text)} (reference run_cross_dataset_eval.py:106)."""
+    recs = []
+    for k, n in enumerate(lens):
+        g = torch.Generator().manual_seed(seed + k)
+        spec = torch.randn(1, 80, n, generator=g)
+        words = ["onl", "k", "kl", "th", "on", "onl"]       # pieces the toy model actually emits: WERs below 1
+        gold = " ".join(words[int(v)] for v in torch.randint(0, len(words), (max(2, n // 60),), generator=g))
+        recs.append({'spec': spec, 'text': gold, 'process_fn': lambda r: (r['spec'], r['text'])})
+    return recs

@@ -56,7 +56,7 @@ from oracle.conformer_ref import SCConformerXLRef  # noqa: E402
 from oracle.madgrad_ref import MADGRAD  # noqa: E402
 
 from loop_pin_cases import *  # noqa: E402,F401,F403
-from loop_pin_cases import (AWMC_CASES, CONCAT_CASES, DYNEVAL_CASES, SU_CASES, OracleGreedyCTCDecoder, StoredMaskSpecAugment, _Inert,
+from loop_pin_cases import (AWMC_CASES, CONCAT_CASES, CROSS_CASES, toy_records, DYNEVAL_CASES, SU_CASES, OracleGreedyCTCDecoder, StoredMaskSpecAugment, _Inert,
                             params_digest, quiet, tokenizer_128, toy_args, toy_model, VOCAB, TOY)  # noqa: E402
 
 
@@ -145,6 +145,32 @@ def main():
         for k, u in enumerate(out):
             arrays[f"su_{tag}_probs{k}"] = u['probs'].numpy()
         meta["su"][tag] = {"args": kw, "lr": lr, "model_seed": 31, "utt_seed": 41, "random_seed": 5, "n": len(out)}
+
+    # ---- the outer loop of BASELINE config 5 (lcasr/run_cross_dataset_eval.py:82-218: transcribe_from_logits, baseline_args, the repeat loop)
+    from make_reference_pins import ref_statements
+    from dynamic_asr_eval_amd.wer import basic_normalize
+    from oracle.wer_ref import word_error_rate_detail
+    code = [ref_statements("lcasr/run_cross_dataset_eval.py", 82, 94), ref_statements("lcasr/run_cross_dataset_eval.py", 96, 218)]
+    meta["cross"] = {}
+    for tag, lens_a, lens_b, kw in CROSS_CASES:
+        model = toy_model(seed=24)
+        args = toy_args(dataset="toy_a", dataset2="toy_b", **kw)
+        scored = []
+
+        def wer_recording(hypotheses, references):
+            scored.append(list(hypotheses))
+            return word_error_rate_detail(hypotheses=hypotheses, references=references)
+        env = {"torch": torch, "argparse": argparse, "tqdm": lambda it, **k: it, "pickle": None, "args": args, "model": model,
+               "data_a": toy_records(lens_a, 400), "data_b": toy_records(lens_b, 500), "eval_fn": ns["dynamic_eval_ctc_loss"], "tokenizer": tok,
+               "beamsearch": None, "beams": 20, "decoder": OracleGreedyCTCDecoder(tok, VOCAB), "normalize": basic_normalize,
+               "word_error_rate_detail": wer_recording, "original_model_params": [p.clone().detach().cpu() for p in model.parameters()],
+               "adapt_overlap": kw["adapt_overlap"] if kw["adapt_overlap"] is not None else kw["overlap"]}
+        with contextlib.redirect_stdout(io.StringIO()):
+            for c in code:
+                exec(c, env)
+        r = env["results"]
+        meta["cross"][tag] = {"lens_a": list(lens_a), "lens_b": list(lens_b), "args": kw, "model_seed": 24, "seeds": [400, 500],
+                              "results": {k: r[k] for k in ("a_baseline", "b_baseline", "a_to_b", "a_to_a_loo")}, "scored_hypotheses": scored}
 
     np.savez_compressed(os.path.join(HERE, "loop_pins.npz"), **arrays)
     json.dump(meta, open(os.path.join(HERE, "loop_pins.json"), "w"), indent=1)

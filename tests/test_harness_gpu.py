@@ -234,3 +234,57 @@ def test_run_cross_speaker_gender(cuda, tmp_path, capsys):
     assert len(d["male_to_male"]) == 2 and len(d["female_to_male"]) == 2 and "wer" in d["male_to_female"][0]
     out = capsys.readouterr().out
     assert "Male baseline WER" in out and "Female baseline WER" in out and "2 female, 2 male" in out
+
+
+def test_run_cross_dataset_matches_the_oracle_outer_loop(cuda, tmp_path, monkeypatch):
+    """BASELINE config 5 above plumbing level (VERDICT r03 missing 1): the harness's whole flow — baselines over A and B at epochs 0, per i:
+    adapt on A[i] with the ADAPT overlap and return_params, load the parameters, evaluate all of B and A minus {i}, restore — against
+    oracle/cross_dataset_ref.py (the restatement of reference lcasr/run_cross_dataset_eval.py:92-218 that tests/golden/loop_pins pins to the
+    reference's own statements) driving oracle.dynamic_eval_ref on the CPU with the same weights and stored SpecAugment masks.  Held: every
+    scored corpus' transcripts in the reference's scoring order, and the four result entries (integer edit counters -> identical rates)."""
+    from dynamic_asr_eval_amd import datasets as D, lib, run_cross_dataset_eval as X
+    from dynamic_asr_eval_amd.decoding import GreedyCTCDecoder as _unused  # noqa: F401  (import check: the harness' decoder module)
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    from dynamic_asr_eval_amd.wer import basic_normalize
+    from oracle import dynamic_eval_ref as R
+    from oracle.conformer_ref import SCConformerXLRef
+    from oracle.cross_dataset_ref import cross_dataset_ref, oracle_eval_fn
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from oracle.wer_ref import word_error_rate_detail
+    monkeypatch.setitem(D.datasets_functions, "toy_a", lambda split: D.get_text_and_audio_synthetic(split, durations_s=[9.0, 12.5, 7.0], seed=611))
+    monkeypatch.setitem(D.datasets_functions, "toy_b", lambda split: D.get_text_and_audio_synthetic(split, durations_s=[8.0, 10.5], seed=733))
+    ckpt = _ckpt(tmp_path, cuda)
+    save = str(tmp_path / "x5.pkl")
+    args = lib.apply_args(X.build_parser(), ["-d", "toy_a", "-d2", "toy_b", "-split", "dev", "-s", save, "-ao", "384", "-c", ckpt, "-seq", "512",
+                                             "-o", "256", "-ds", "-nv", "-epochs", "1", "-kwargs", "optim_lr=2e-5", "vocab_size=128", "quiet=True"])
+    g = torch.Generator().manual_seed(77)
+    masks = {k: (R.draw_masks(2, 10, 80, g), ([], [])) for k in range(0, 2048, 128)}      # every window key of both overlaps
+    args.spec_augment_fixed_masks = masks
+    scored = []
+    real_score = X.score_texts
+
+    def recording_score(preds, golds, reduce_over_ranks=False):
+        scored.append(list(preds))
+        return real_score(preds, golds, reduce_over_ranks=reduce_over_ranks)
+    monkeypatch.setattr(X, "score_texts", recording_score)
+    X.main(args)
+    got = pickle.load(open(save.replace(".pkl", "_1.pkl"), "rb"))
+
+    state = torch.load(ckpt, map_location="cpu", weights_only=True)
+    ref = SCConformerXLRef(dict(state["config"]["model"]), vocab_size=128)
+    ref.load_state_dict(state["model"])
+    ref.device = torch.device("cpu")
+    tok = SyntheticTokenizer(128)
+    oargs = argparse.Namespace(**{k: v for k, v in vars(args).items()})
+    eval_fn = oracle_eval_fn(MADGRAD_REF, lib.get_lr_args_from_args, lambda a: {}, lambda spec, sl, ov: masks)
+    want_scored = []
+    want = cross_dataset_ref(oargs, ref, D.datasets_functions["toy_a"]("dev"), D.datasets_functions["toy_b"]("dev"), eval_fn, tok,
+                             lambda logits: basic_normalize(tok.decode(R.greedy_ctc_ids(torch.as_tensor(logits), 128))).lower(),
+                             word_error_rate_detail, record=want_scored, device_copies=True)[0]
+    assert len(scored) == len(want_scored) == 2 + 2 * 3
+    for k, (hyps, (phase, i, ref_hyps)) in enumerate(zip(scored, want_scored)):
+        assert hyps == ref_hyps, f"corpus {k} ({phase}, i = {i}): transcripts differ from the oracle's"
+    assert sum(len(h.split()) for hyps in scored for h in hyps) > 50, "the comparison must be over non-empty transcripts"
+    assert len({tuple(h) for h in scored[2::2]}) > 1, "adapting on different A[i] must change B's transcripts, or the test shows nothing"
+    for k in ("a_baseline", "b_baseline", "a_to_b", "a_to_a_loo"):
+        assert got[k] == want[k], (k, got[k], want[k])

@@ -353,3 +353,42 @@ def test_oracle_wav2vec2_su_loop_reproduces_the_reference_function(loop_pins):
             if k:
                 moved = max(moved, float(np.abs(want).max()))
         assert moved > 0
+
+
+def test_oracle_cross_dataset_loop_reproduces_the_reference_statements(loop_pins):
+    """BASELINE config 5's outer loop: reference lcasr/run_cross_dataset_eval.py:82-94,96-218 executed unchanged on toy recordings
+    (eval_fn = the reference's own dynamic_eval_ctc_loss) against oracle/cross_dataset_ref.py driving oracle.dynamic_eval_ref: every scored
+    corpus' hypotheses in scoring order, and the four result entries."""
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.wer import basic_normalize
+    from oracle import dynamic_eval_ref as R
+    from oracle.cross_dataset_ref import cross_dataset_ref, oracle_eval_fn
+    from oracle.madgrad_ref import MADGRAD
+    from oracle.wer_ref import word_error_rate_detail
+    arr, meta, C, same = loop_pins
+    tok = C.tokenizer_128()
+    dec = C.OracleGreedyCTCDecoder(tok, C.VOCAB)
+    for tag, lens_a, lens_b, kw in C.CROSS_CASES:
+        m = meta["cross"][tag]
+        assert (m["lens_a"], m["lens_b"], m["args"]) == (list(lens_a), list(lens_b), kw)
+        model = C.toy_model(seed=m["model_seed"])
+        before = [p.clone() for p in model.parameters()]
+        args = C.toy_args(dataset="toy_a", dataset2="toy_b", **kw)
+        eval_fn = oracle_eval_fn(MADGRAD, lib.get_lr_args_from_args, lib.get_specaugment_config_from_args,
+                                 lambda spec, sl, ov: _fixed_masks(C, spec, sl, ov))
+        transcribe = lambda logits: basic_normalize(dec(torch.as_tensor(logits))).lower()   # noqa: E731
+        # (1) as the statements evaluate on the CPU, where `.to(p.device)` aliases (oracle/cross_dataset_ref.py docstring): the pin's own mode
+        scored = []
+        res = cross_dataset_ref(args, model, C.toy_records(lens_a, m["seeds"][0]), C.toy_records(lens_b, m["seeds"][1]), eval_fn, tok,
+                                transcribe, word_error_rate_detail, record=scored, device_copies=False)
+        assert [h for _, _, h in scored] == m["scored_hypotheses"], f"{tag}: hypotheses differ from the reference's run"
+        assert [p for p, _, _ in scored] == ["a_baseline", "b_baseline"] + ["a_to_b", "a_to_a_loo"] * len(lens_a)
+        for k in ("a_baseline", "b_baseline", "a_to_b", "a_to_a_loo"):
+            assert res[0][k] == m["results"][k], (tag, k)
+        # (2) with copies, as on a GPU: the baselines and iteration 0 are the same numbers, and the weights really come back
+        model = C.toy_model(seed=m["model_seed"])
+        res2 = cross_dataset_ref(args, model, C.toy_records(lens_a, m["seeds"][0]), C.toy_records(lens_b, m["seeds"][1]), eval_fn, tok,
+                                 transcribe, word_error_rate_detail, device_copies=True)
+        assert res2[0]["a_baseline"] == m["results"]["a_baseline"] and res2[0]["b_baseline"] == m["results"]["b_baseline"]
+        assert res2[0]["a_to_b"][0] == m["results"]["a_to_b"][0] and res2[0]["a_to_a_loo"][0] == m["results"]["a_to_a_loo"][0]
+        assert all(torch.equal(a, b) for a, b in zip(before, model.parameters())), "weights restored after the last i (:197-198)"
