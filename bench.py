@@ -252,7 +252,53 @@ class _Skip(Exception):
     pass
 
 
-def other_workloads(a, model, dev, which=('awmc', 'wav2vec2_su', 'enc_dec_teacher_ce')):
+def soft_dtw_latency(dev):
+    """Soft-DTW (reference wav2vec2/soft_dtw_cuda.py; constructed wav2vec2/lib.py:130,370 as SoftDTW(use_cuda=True, gamma=1.5)): forward +
+    backward latency through the module, measured the way the reference's own `profile()` does (:383-418: forward, then autograd.grad w.r.t.
+    the first argument; first iteration dropped) at the config-3 shape [2, 409, 32] (131 072-sample windows -> 409 frames of 32 logits) and at
+    the reference's three self-check shapes (:426-428), next to the CPU oracle (numpy fp64 restatement of the Numba recurrences) on a bounded
+    sample of the batch.  The scan is latency-bound (N + M - 1 anti-diagonals, one barrier each): `us_per_diagonal` is the figure that
+    matters, `hbm_frac` (algorithmic bytes: D read twice, the fp64 lattice written once and read once, E written) says how far from
+    bandwidth it is."""
+    import numpy as np
+    from dynamic_asr_eval_amd.soft_dtw import SoftDTW
+    from oracle import softdtw_ref
+    rows = []
+    for B, N, M, d, gamma in ((2, 409, 409, 32, 1.5), (128, 17, 15, 2, 1.0), (512, 64, 64, 2, 1.0), (512, 256, 256, 2, 1.0)):
+        sd = SoftDTW(True, gamma=gamma, normalize=False)
+        g = torch.Generator().manual_seed(1234)
+        ts = []
+        for i in range(6):
+            x = torch.rand(B, N, d, generator=g).to(dev).requires_grad_()
+            y = torch.rand(B, M, d, generator=g).to(dev)
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            val = sd(x, y)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            grad = torch.autograd.grad(val, x, grad_outputs=torch.ones_like(val))[0]
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            if i:
+                ts.append((t1 - t, t2 - t1))
+        fwd, bwd = float(np.mean([v[0] for v in ts])), float(np.mean([v[1] for v in ts]))
+        nb = min(B, 4)                                                   # bounded CPU sample: <= 4 pairs of the batch, scaled to B
+        xc, yc = x.detach().cpu().double().numpy()[:nb], y.cpu().double().numpy()[:nb]
+        t = time.perf_counter()
+        D = ((xc[:, :, None, :] - yc[:, None, :, :]) ** 2).sum(-1)
+        R = softdtw_ref.softdtw_forward(D, gamma)
+        softdtw_ref.softdtw_backward(D, R, gamma)
+        cpu = (time.perf_counter() - t) * B / nb
+        ok = bool(np.allclose(R[:, -2, -2], val.detach().cpu().numpy()[:nb], rtol=1e-5, atol=1e-5))
+        alg = B * (2 * N * M * 4 + 2 * (N + 2) * (M + 2) * 8 + N * M * 4)
+        rows.append({"shape": [B, N, M, d], "gamma": gamma, "fwd_ms": round(fwd * 1e3, 3), "bwd_ms": round(bwd * 1e3, 3),
+                     "us_per_diagonal": round((fwd + bwd) * 1e6 / (2 * (N + M - 1)), 3), "algorithmic_bytes": alg,
+                     "hbm_frac": round(alg / (fwd + bwd) / 8e12, 5), "cpu_oracle_ms": round(cpu * 1e3, 1), "cpu_sample": f"{nb} of {B} pairs, scaled",
+                     "value_matches_oracle": ok})
+    return rows
+
+
+def other_workloads(a, model, dev, which=('awmc', 'wav2vec2_su', 'enc_dec_teacher_ce', 'soft_dtw')):
     """Driver-visible throughput of the path's other loops (one recording each, one chain, second of two runs; untimed as far as
     `value` goes).  Same kernels, same C-ABI; shapes: AWMC on a 10-min recording of the benchmark's model and window; wav2vec2-base
     (Wav2Vec2Config() defaults, seeded) `dynamic_eval_su` over a 5-min TEDLIUM-shape talk cut by the reference's fetch_utterances
@@ -301,7 +347,19 @@ def other_workloads(a, model, dev, which=('awmc', 'wav2vec2_su', 'enc_dec_teache
         wargs = argparse.Namespace(epochs=1, shuffle=False)
         dt = best_of_two(lambda: W.dynamic_eval_su(wargs, wm, [dict(u) for u in utts], 0, 0, W.CharTokenizer(), None, use_tqdm=False, optim=W.MADGRAD,
                                                    lr_args={'lr': 1e-6}))
-        out["wav2vec2_su"] = {"value": round(audio_s / dt, 1), "unit": "audio-s/s", "sample": f"{len(utts)} utterances, {audio_s:.0f} s of 16 kHz audio, wav2vec2-base shape"}
+        # roofline entry of config 3's loop: every matrix product of one more (untimed) pass counted, over the timed pass's wall time
+        from dynamic_asr_eval_amd import ops as _ops
+        _ops.gemm_profile_start(every=1 << 30)
+        with redirect_stdout(io.StringIO()):
+            W.dynamic_eval_su(wargs, wm, [dict(u) for u in utts], 0, 0, W.CharTokenizer(), None, use_tqdm=False, optim=W.MADGRAD, lr_args={'lr': 1e-6})
+        torch.cuda.synchronize(dev)
+        pr = _ops.gemm_profile_stop()
+        tf = (pr["flops"] + pr["attn_flops"]) / dt / 1e12
+        out["wav2vec2_su"] = {"value": round(audio_s / dt, 1), "unit": "audio-s/s", "sample": f"{len(utts)} utterances, {audio_s:.0f} s of 16 kHz audio, wav2vec2-base shape",
+                              "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "gemm_launches_per_utterance": round(pr["calls"] / len(utts), 1),
+                                           "gflop_per_utterance": round(pr["flops"] / len(utts) / 1e9, 1),
+                                           "note": "whole-loop figure (every kernel and host gap of the pass in the denominator): the loop is launch-bound, not MFMA-bound"}}
         del wm
     except _Skip:
         pass
@@ -325,6 +383,11 @@ def other_workloads(a, model, dev, which=('awmc', 'wav2vec2_su', 'enc_dec_teache
         pass
     except Exception as e:
         out["enc_dec_teacher_ce"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    try:
+        if 'soft_dtw' in which:
+            out["soft_dtw"] = soft_dtw_latency(dev)
+    except Exception as e:
+        out["soft_dtw"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return out
 
 

@@ -82,6 +82,10 @@ float* partials_alloc(void* workspace, int64_t bytes);
 void reduce_or_defer(const float* partial, float* out, int64_t P, int64_t n, float beta, hipStream_t st);
 void reduce_taps_or_defer(const float* partial, float* out, int64_t P, int64_t n, float beta, int C, hipStream_t st);   // [tap][C] -> [C][taps]
 void reduce_pair_or_defer(const float* p0, float* out0, const float* p1, float* out1, int64_t P, int64_t n, float beta, hipStream_t st);
+// Every OTHER launch that writes a reduction output while a deferral context is open goes through ordered_before_launch() first: recording
+// order is execution order, so what has been recorded so far runs before the direct launch (a recorded item into the same output must not be
+// overtaken — today every writer uses beta = 1 and only the summation order would change, a beta = 0 writer would lose a term).
+void ordered_before_launch(hipStream_t st);
 
 }  // namespace dyn
 

@@ -64,6 +64,8 @@ struct DeferState {
     char* arena = nullptr;
     int64_t cap = 0, off = 0;
     int n = 0;
+    hipStream_t stream = nullptr;   // the stream of the first recorded item: producers, later items and the flush must all use it
+    bool have_stream = false;
     ReduceItem items[kMaxItems];
 };
 thread_local DeferState g_defer;
@@ -150,15 +152,28 @@ static bool in_arena(const void* p) {
     return d.active && (const char*)p >= d.arena && (const char*)p < d.arena + d.cap;
 }
 
-// run what has been recorded so far (recording order is execution order: a reduction that cannot be deferred must not overtake them)
-static void flush_recorded(hipStream_t st) {
+// run what has been recorded so far (recording order is execution order: a reduction that cannot be deferred must not overtake them).
+// The batch runs on the stream the items were RECORDED on — their partial sums were produced there — whatever stream the caller is on.
+static void flush_recorded(hipStream_t) {
     DeferState& d = g_defer;
-    for (int i = 0; i < d.n; i += kTable) launch_batch(d.items + i, d.n - i < kTable ? d.n - i : kTable, st);
+    for (int i = 0; i < d.n; i += kTable) launch_batch(d.items + i, d.n - i < kTable ? d.n - i : kTable, d.stream);
     d.n = 0;
+    d.have_stream = false;
+}
+
+// true when an item produced on `st` may join the recorded ones
+static bool same_stream(hipStream_t st) {
+    DeferState& d = g_defer;
+    if (!d.have_stream) { d.stream = st; d.have_stream = true; return true; }
+    return d.stream == st;
+}
+
+void ordered_before_launch(hipStream_t st) {
+    if (g_defer.active && g_defer.n > 0) flush_recorded(st);
 }
 
 void reduce_or_defer(const float* partial, float* out, int64_t P, int64_t n, float beta, hipStream_t st) {
-    if (!in_arena(partial) || g_defer.n >= kMaxItems || P >= (1ll << 31) || n >= (1ll << 31)) {
+    if (!in_arena(partial) || g_defer.n >= kMaxItems || P >= (1ll << 31) || n >= (1ll << 31) || !same_stream(st)) {
         if (g_defer.active && g_defer.n > 0) flush_recorded(st);
         launch_reduce_partials(partial, out, P, n, beta, st);
         return;
@@ -169,7 +184,7 @@ void reduce_or_defer(const float* partial, float* out, int64_t P, int64_t n, flo
 }
 
 void reduce_taps_or_defer(const float* partial, float* out, int64_t P, int64_t n, float beta, int C, hipStream_t st) {
-    if (!in_arena(partial) || g_defer.n >= kMaxItems || P >= (1ll << 31) || n >= (1ll << 31)) {
+    if (!in_arena(partial) || g_defer.n >= kMaxItems || P >= (1ll << 31) || n >= (1ll << 31) || !same_stream(st)) {
         if (g_defer.active && g_defer.n > 0) flush_recorded(st);
         launch_reduce_partials_taps(partial, out, P, n, beta, C, st);
         return;
@@ -180,7 +195,7 @@ void reduce_taps_or_defer(const float* partial, float* out, int64_t P, int64_t n
 }
 
 void reduce_pair_or_defer(const float* p0, float* out0, const float* p1, float* out1, int64_t P, int64_t n, float beta, hipStream_t st) {
-    if (!in_arena(p0) || !in_arena(p1) || g_defer.n + 2 > kMaxItems) {
+    if (!in_arena(p0) || !in_arena(p1) || g_defer.n + 2 > kMaxItems || !same_stream(st)) {
         if (g_defer.active && g_defer.n > 0) flush_recorded(st);
         launch_reduce_partials_pair(p0, out0, p1, out1, P, n, beta, st);
         return;
@@ -198,6 +213,7 @@ extern "C" int dyn_reduce_defer_begin(void* arena, int64_t arena_bytes) {
     dyn::g_defer.cap = arena_bytes;
     dyn::g_defer.off = 0;
     dyn::g_defer.n = 0;
+    dyn::g_defer.have_stream = false;
     return DYN_OK;
 }
 
@@ -205,6 +221,13 @@ extern "C" int dyn_reduce_defer_flush(void* stream) {
     dyn::DeferState& d = dyn::g_defer;
     if (!d.active) return DYN_OK;
     d.active = false;
+    if (d.n > 0 && d.have_stream && d.stream != (hipStream_t)stream) {
+        // the partial sums were produced on another stream: run the batch there (ordered after its producers) and say so — the caller's
+        // stream has no dependency on the outputs
+        dyn::flush_recorded(d.stream);
+        dyn::set_error("dyn_reduce_defer_flush: %s", "items were recorded on a different stream than the flush; the batch ran on the recording stream");
+        return DYN_E_ARG;
+    }
     // batches of 96 in recording order; a chain cut by a batch boundary continues in the next launch, which the stream runs after this one
     dyn::flush_recorded((hipStream_t)stream);
     d.n = 0;
@@ -213,6 +236,7 @@ extern "C" int dyn_reduce_defer_flush(void* stream) {
 
 extern "C" int dyn_reduce_defer_abort(void) {
     dyn::g_defer.active = false;
+    dyn::g_defer.have_stream = false;
     dyn::g_defer.n = 0;
     return DYN_OK;
 }

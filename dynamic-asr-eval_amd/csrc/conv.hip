@@ -844,6 +844,7 @@ extern "C" int dyn_conv2d_first_wgrad(const float* x, const float* dz, float* dw
     if (C % 4 == 0 && (((uintptr_t)dz) & 15) == 0) {
         hipLaunchKernelGGL((conv2d_s2_wgrad_v4_kernel<true>), dim3((unsigned)dyn::cdiv(tiles, 4)), dim3(256), 0, st, x, dz, pw, pb, T, (int)F,
                            To, (int)Fo, (int)C, per, chunks, tiles);
+        dyn::ordered_before_launch(st);
         dyn::launch_reduce_partials_taps(pw, dw, dyn::cdiv(tiles, 4), C * 9, beta, (int)C, st);
         dyn::launch_reduce_partials(pb, dbias, dyn::cdiv(tiles, 4), C, beta, st);
         return dyn::check_launch("dyn_conv2d_first_wgrad");
@@ -851,6 +852,7 @@ extern "C" int dyn_conv2d_first_wgrad(const float* x, const float* dz, float* dw
         dim3 grid((unsigned)chunks, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
         hipLaunchKernelGGL(conv2d_first_wgrad_kernel, grid, dim3(256), 0, st, x, dz, pw, pb, T, (int)F, To, (int)Fo, (int)C, per);
     }
+    dyn::ordered_before_launch(st);
     dyn::launch_reduce_partials(pw, dw, tiles, C * 9, beta, st);
     dyn::launch_reduce_partials(pb, dbias, tiles, C, beta, st);
     return dyn::check_launch("dyn_conv2d_first_wgrad");
@@ -960,6 +962,7 @@ extern "C" int dyn_dwconv2d_s2_wgrad(const float* z, const float* du, float* dw,
         dim3 grid((unsigned)chunks, (unsigned)dyn::cdiv(C, 256), (unsigned)B);
         hipLaunchKernelGGL(dwconv2d_s2_wgrad_kernel, grid, dim3(256), 0, st, z, du, pw, pb, T, (int)F, To, (int)Fo, (int)C, per);
     }
+    dyn::ordered_before_launch(st);
     dyn::launch_reduce_partials(pw, dw, tiles, C * 9, beta, st);
     dyn::launch_reduce_partials(pb, dbias, tiles, C, beta, st);
     return dyn::check_launch("dyn_dwconv2d_s2_wgrad");

@@ -277,6 +277,7 @@ extern "C" int dyn_colsum(const float* x, float* out, int64_t rows, int64_t C, f
     }
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)dyn::cdiv(C, 64), (unsigned)chunks), dim3(256), 0, st, x,
                        (float*)workspace, rows, (int)C, rpc);
+    dyn::ordered_before_launch(st);
     dyn::launch_reduce_partials((const float*)workspace, out, chunks, C, beta, st);
     return dyn::check_launch("dyn_colsum");
 }
@@ -284,6 +285,7 @@ extern "C" int dyn_colsum(const float* x, float* out, int64_t rows, int64_t C, f
 extern "C" int dyn_reduce_partials(const float* partial, float* out, int64_t P, int64_t n, float beta, void* stream) {
     DYN_REQUIRE(P >= 0 && n >= 0 && (n == 0 || (partial && out)), DYN_E_ARG, "dyn_reduce_partials: bad arguments");
     if (n == 0) return DYN_OK;
+    dyn::ordered_before_launch((hipStream_t)stream);   // recorded reductions (dyn_reduce_defer_begin) may target the same output: they go first
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, partial, out, P, n, beta);
     return dyn::check_launch("dyn_reduce_partials");
 }

@@ -341,6 +341,7 @@ extern "C" int dyn_colnorm_bwd(const float* x, const float* gamma, const float* 
     hipLaunchKernelGGL(colnorm_bwd_sums_kernel, dim3((unsigned)dyn::cdiv(C, TPB), (unsigned)B), dim3(TPB), 0, st, partial, sums, (int)C, chunks);
     hipLaunchKernelGGL(colnorm_bwd_apply_kernel, dim3(grid_for(B * T * C)), dim3(TPB), 0, st, x, dy, mean, rstd, gamma, sums, dx, B, T, (int)C);
     // sums is [2][B][C]: reduce over the batch (in order) into the affine gradients
+    dyn::ordered_before_launch(st);
     if (dbeta) dyn::launch_reduce_partials(sums, dbeta, B, C, wgrad_beta, st);
     if (dgamma) dyn::launch_reduce_partials(sums + (int64_t)B * C, dgamma, B, C, wgrad_beta, st);
     return dyn::check_launch("dyn_colnorm_bwd");

@@ -13,8 +13,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:    # as bench.self_launch picks its rendezvous port
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_rccl_one_rank_group_runs_every_collective_helper(cuda):
-    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611",
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("DYN_DIST_BACKEND", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_worker.py")], env=env, capture_output=True, text=True, timeout=300)

@@ -153,20 +153,21 @@ def test_multi_window_drift_against_the_oracle_and_its_float64_noise_floor(cuda)
     windows (overlap 14336) + the short tail window of one recording at 6 x 768 / V+1 = 4096, stored masks, lr 9e-5, through
     lib.dynamic_eval (online and offline) against oracle/dynamic_eval_ref.py — and against THE SAME ORACLE RUN IN FLOAT64.
 
-    Why three ways: after 9 carried MADGRAD steps the fp32 CPU oracle is itself ~2e-3 away from its own float64 run (the fp32
-    log-space CTC lattice at |alpha| ~ 3000 puts one common factor of a few 1e-3 on the whole gradient — in torch.nn.CTCLoss on the
-    CPU exactly as in dyn_ctc_loss — and the cube root in MADGRAD's step carries it into the weights; DESIGN.md section 4,
-    profiles/r03_drift.json).  Two fp32 realisations of a chaotic 9-step recursion cannot be held closer to each other than each is to
-    the exact arithmetic, and which of them lands inside 1e-3 depends on the recording (6.7e-4 on bench.py's, 1.6e-3 and 8.6e-4 on two
-    others).  So the bar is asserted where it is a property of the implementation rather than of the draw:
-      * strictly < 1e-3 on the rows the FIRST window takes part in (online bands 0..8: the clean-copy posteriors of all 9 adapt steps
-        are averaged there);
-      * everywhere (offline final pass and online): |hip - f32 oracle| <= max(1e-3, 2 x |f32 oracle - f64 oracle|) — inside the
-        literal bar whenever the reference's own arithmetic is, never further from the reference than twice the reference's own
-        distance from exact arithmetic;
-      * argmax ids identical except at near-ties of the oracle (margin < 5e-5); and a 1e-2 sanity bound (a real defect is > 1e-2).
-    One MADGRAD step at this shape is held to the literal 1e-3 by the test above; bench.py prints this same comparison for its own
-    recording in every run (`parity`)."""
+    r04: `dyn_ctc_loss` is now BIT-IDENTICAL to torch's CPU CTC on identical log-probs (tests/test_ops_gpu.py::
+    test_ctc_lattice_is_bitwise_torch_cpu: nll, every alpha cell, every gradient element), so what is left between the two fp32 runs
+    is not a property of either implementation's arithmetic: their log-probs differ by ~1e-6 (GEMM summation order), and the fp32
+    log-space lattice at |alpha| ~ 3000 - 4600 (ulp 2.4e-4 - 4.9e-4; a seeded model labelling noise is a worst case: ~2 nats per
+    frame) is CHAOTIC in its inputs — a 1e-6 change flips a rounding every few hundred steps, each flip moves alpha by one ulp, and the
+    random walk of those flips is a common factor of 1e-3 - 4e-3 on the whole gradient (profiles/r04_drift_s77.json `grad_diag`: HIP
+    3.5e-3, torch-CPU 2.3e-3 from float64 — two draws from one distribution).  MADGRAD's cube root carries that into the weights; after
+    9 carried steps the fp32 oracle is itself 1.7e-3 - 6.2e-3 away from its own float64 run and the HIP path lands 4.5e-4 - 4.1e-3
+    from the fp32 oracle depending on the recording (profiles/r04_drift_s{77,78,1234}.json).  So:
+      * the literal 1e-3 of BASELINE.json is asserted where it is a property of the implementation: one adapt step (test above), the rows
+        the FIRST window takes part in (online bands 0..8), and the whole of bench.py's own parity recording (seed 1234: 4.5e-4 offline,
+        5.6e-4 online) — `test_bench_recording_is_inside_the_literal_bar` below;
+      * on this recording (seed 78) the three-way rule: |hip - f32 oracle| <= max(1e-3, 2 x |f32 oracle - f64 oracle|), capped at 1e-2
+        (a real defect is > 1e-2) — never further from the reference than twice the reference's own distance from exact arithmetic;
+      * argmax ids identical except at near-ties of the oracle (margin < 5e-5)."""
     import argparse
     from oracle import dynamic_eval_ref as R
     from oracle.conformer_ref import SCConformerXLRef
@@ -205,7 +206,44 @@ def test_multi_window_drift_against_the_oracle_and_its_float64_noise_floor(cuda)
         curve = [float(f"{d[k:k + band].max():.2e}") for k in range(0, d.shape[0], band)]
         print(f"drift {name}: |hip - f32| per {band}-row band {curve}; |f32 - f64| = {floor:.2e}")
         assert d.max() < 1e-2, f"{name}: {d.max()} — not a rounding effect"
-        assert d.max() <= max(1e-3, 2.0 * floor), f"{name}: |hip - f32| = {d.max():.2e} with the oracle's own float64 distance at {floor:.2e}: {curve}"
+        assert d.max() <= min(1e-2, max(1e-3, 2.0 * floor)), f"{name}: |hip - f32| = {d.max():.2e} with the oracle's own float64 distance at {floor:.2e}: {curve}"
         if name == "online":
             assert d[:9 * band].max() < 1e-3, f"online, rows of the first window: {curve[:9]}"
         _argmax_check(torch.from_numpy(got), torch.from_numpy(want), f"drift {name}")
+
+
+def test_bench_recording_is_inside_the_literal_bar(cuda):
+    """The recording bench.py's `parity` object is computed on (synthetic_spec seed 1234, mask seed 99, blank bias 0: 8 windows + tail, 9
+    carried MADGRAD steps at 6 x 768 / V+1 = 4096): adapted, stitched log-probs within the LITERAL 1e-3 of the fp32 CPU oracle, offline and
+    online, argmax ids identical (keep the literal bar as a hard assertion on a committed seed)."""
+    import argparse
+    from oracle import dynamic_eval_ref as R
+    from oracle.conformer_ref import SCConformerXLRef
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.datasets import synthetic_spec
+    from dynamic_asr_eval_amd.model import SCConformerXL
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = SCConformerXLRef(vocab_size=VOCAB, seed=0, blank_bias=0.0)
+    hip = SCConformerXL(vocab_size=VOCAB, device=cuda)
+    hip.load_state_dict(ref.state_dict())
+    OVL, NWIN = 14336, 8
+    tok = SyntheticTokenizer(VOCAB)
+    spec = synthetic_spec(SEQ + (NWIN - 1) * (SEQ - OVL), seed=1234)
+    _, keys = R.prepare_chunks(spec, SEQ, OVL)
+    g = torch.Generator().manual_seed(99)
+    masks = {k: (R.draw_masks(6, 34, 80, g), ([], [])) for k in keys}
+
+    def args(online):
+        ns = argparse.Namespace(config={'model': {'subsampling_factor': 8}, 'audio_chunking': {'size': SEQ, 'overlap': 0}, 'training': {}})
+        ns.__dict__.update(dict(optim_lr=9e-5, epochs=1, shuffle=False, online=online, quiet=True, spec_augment_fixed_masks=masks))
+        return ns
+    f32_off, f32_on = R.dynamic_eval_ref(ref, spec, SEQ, OVL, tok, MADGRAD_REF, {'lr': 9e-5}, {}, fixed_masks=masks, also_online=True)
+    got_off = lib.dynamic_eval(args(False), hip, spec, SEQ, OVL, tok, use_tqdm=False)
+    got_on = lib.dynamic_eval(args(True), hip, spec, SEQ, OVL, tok, use_tqdm=False)
+    for name, got, want in (("offline", got_off, f32_off), ("online", got_on, f32_on)):
+        d = float(np.abs(got - want).max())
+        print(f"bench recording, {name}: max |dlogp| = {d:.2e}")
+        assert d < 1e-3, f"{name}: {d:.3e}"
+        assert np.array_equal(got.argmax(-1), want.argmax(-1)), name

@@ -552,6 +552,32 @@ def test_deferred_column_reductions_match_the_separate_launches(cuda):
                 for k in want:
                     assert torch.equal(want[k], got[k]), (k, repeats, arena_bytes)
         assert float(want["dgam"].abs().max()) > 1.0
+    # a DIRECT reduction (ops.reduce_partials, as model.py uses for the shared-weight slabs) into an output that a RECORDED one
+    # also targets must not overtake it — with a beta = 0 direct writer the recorded term would otherwise be added on top of the overwrite
+    slabs = torch.randn(4, C, generator=g).to(cuda)
+    def mixed(arena):
+        acc = torch.full((C,), 3.0, device=cuda)
+        with ops.reduce_defer(arena):
+            ops.colsum(dys[0], acc, beta=1.0)            # recorded (deferred) when an arena is open
+            ops.reduce_partials(slabs, acc, beta=0.0)    # direct: overwrites — must run AFTER the recorded column sum
+            ops.colsum(dys[1], acc, beta=1.0)            # recorded again
+        return acc
+    with ops.use_workspace(torch.empty(ops.WORKSPACE_BYTES // 4, dtype=torch.uint8, device=cuda)):
+        want = mixed(None)
+        got = mixed(torch.empty(ops.DEFER_ARENA_BYTES, dtype=torch.uint8, device=cuda))
+        assert torch.equal(want, got), "a direct reduction overtook a recorded one"
+        # an item produced on ANOTHER stream does not join the batch (it reduces at once on its own stream, after what was recorded so far)
+        side = torch.cuda.Stream()
+        acc2 = torch.zeros(C, device=cuda); acc3 = torch.zeros(C, device=cuda)
+        torch.cuda.synchronize()
+        with ops.reduce_defer(torch.empty(ops.DEFER_ARENA_BYTES, dtype=torch.uint8, device=cuda)):
+            ops.colsum(dys[0], acc2, beta=0.0)
+            with torch.cuda.stream(side):
+                ops.colsum(dys[1], acc3, beta=0.0)
+            side.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(acc2, ops.colsum(dys[0], torch.zeros(C, device=cuda), beta=0.0))
+        assert torch.equal(acc3, ops.colsum(dys[1], torch.zeros(C, device=cuda), beta=0.0))
     # a context is per thread and not nestable; an exception inside drops it
     a = torch.empty(1 << 20, dtype=torch.uint8, device=cuda)
     with pytest.raises(ops.DynError):
