@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--pcie", type=int, default=0, help="1: recordings start in HOST memory and results come back as numpy (the "
                     "PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
     ap.add_argument("--chains", type=int, default=3, help="independent recordings in flight per GPU (own stream + model replica)")
+    ap.add_argument("--lockstep", type=int, default=1, help="R > 1: every chain is a LOCKSTEP GROUP of R recordings advancing through the same window "
+                    "step in one batch (SCConformerXL(group=R): one launch per layer for all R, each recording with its own weights); chains x R recordings in flight")
     return ap.parse_args()
 
 
@@ -252,6 +254,20 @@ class _Skip(Exception):
     pass
 
 
+def cpu_baseline_soft_dtw(x, y, gamma, value, B):
+    """CPU leg of the soft-DTW figure (part of the cpu_baseline leg: the only place bench.py may touch oracle/): the numpy fp64 restatement
+    of the reference's Numba recurrences timed on a bounded sample (<= 4 pairs of the batch, scaled to B), and the HIP value checked against it."""
+    import numpy as np
+    from oracle import softdtw_ref
+    nb = x.shape[0]
+    t = time.perf_counter()
+    D = ((x[:, :, None, :] - y[:, None, :, :]) ** 2).sum(-1)
+    R = softdtw_ref.softdtw_forward(D, gamma)
+    softdtw_ref.softdtw_backward(D, R, gamma)
+    cpu = (time.perf_counter() - t) * B / nb
+    return cpu, bool(np.allclose(R[:, -2, -2], value[:nb], rtol=1e-5, atol=1e-5))
+
+
 def soft_dtw_latency(dev):
     """Soft-DTW (reference wav2vec2/soft_dtw_cuda.py; constructed wav2vec2/lib.py:130,370 as SoftDTW(use_cuda=True, gamma=1.5)): forward +
     backward latency through the module, measured the way the reference's own `profile()` does (:383-418: forward, then autograd.grad w.r.t.
@@ -262,7 +278,6 @@ def soft_dtw_latency(dev):
     bandwidth it is."""
     import numpy as np
     from dynamic_asr_eval_amd.soft_dtw import SoftDTW
-    from oracle import softdtw_ref
     rows = []
     for B, N, M, d, gamma in ((2, 409, 409, 32, 1.5), (128, 17, 15, 2, 1.0), (512, 64, 64, 2, 1.0), (512, 256, 256, 2, 1.0)):
         sd = SoftDTW(True, gamma=gamma, normalize=False)
@@ -283,13 +298,7 @@ def soft_dtw_latency(dev):
                 ts.append((t1 - t, t2 - t1))
         fwd, bwd = float(np.mean([v[0] for v in ts])), float(np.mean([v[1] for v in ts]))
         nb = min(B, 4)                                                   # bounded CPU sample: <= 4 pairs of the batch, scaled to B
-        xc, yc = x.detach().cpu().double().numpy()[:nb], y.cpu().double().numpy()[:nb]
-        t = time.perf_counter()
-        D = ((xc[:, :, None, :] - yc[:, None, :, :]) ** 2).sum(-1)
-        R = softdtw_ref.softdtw_forward(D, gamma)
-        softdtw_ref.softdtw_backward(D, R, gamma)
-        cpu = (time.perf_counter() - t) * B / nb
-        ok = bool(np.allclose(R[:, -2, -2], val.detach().cpu().numpy()[:nb], rtol=1e-5, atol=1e-5))
+        cpu, ok = cpu_baseline_soft_dtw(x.detach().cpu().double().numpy()[:nb], y.cpu().double().numpy()[:nb], gamma, val.detach().cpu().numpy(), B)
         alg = B * (2 * N * M * 4 + 2 * (N + 2) * (M + 2) * 8 + N * M * 4)
         rows.append({"shape": [B, N, M, d], "gamma": gamma, "fwd_ms": round(fwd * 1e3, 3), "bwd_ms": round(bwd * 1e3, 3),
                      "us_per_diagonal": round((fwd + bwd) * 1e6 / (2 * (N + M - 1)), 3), "algorithmic_bytes": alg,
@@ -408,11 +417,14 @@ def main():
     assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", ddist.local_device_index(local_rank))
     torch.cuda.set_device(dev)
-    n_chains = pick_chains(a.chains, a.steps)
+    R = max(1, a.lockstep)
+    n_chains = pick_chains(a.chains, (a.steps + R - 1) // R)
     models = []
     for _ in range(n_chains):
-        m = SCConformerXL(vocab_size=a.vocab, device=dev)
+        m = SCConformerXL(vocab_size=a.vocab, device=dev, group=R)
         init_synthetic(m, seed=0, blank_bias=0.0)
+        if R > 1:
+            m.load_state_dict(m.state_dict())          # replica 0's seeded weights into every replica of the group
         models.append(m)
     model = models[0]
     plain_tok = SyntheticTokenizer(a.vocab)
@@ -433,7 +445,7 @@ def main():
         run_args = args
         if online is not None and bool(online) != bool(a.online):
             run_args = argparse.Namespace(**vars(args)); run_args.online = bool(online)
-        outs = lib.dynamic_eval_many(run_args, models[:max(1, min(len(models), len(spec_list)))], spec_list, a.seq_len, a.overlap, tokenizer or tok,
+        outs = lib.dynamic_eval_many(run_args, models[:max(1, min(len(models), (len(spec_list) + R - 1) // R))], spec_list, a.seq_len, a.overlap, tokenizer or tok,
                                      use_tqdm=False, return_device=not pcie)
         if pcie:   # the reference's contract: np.float32 [T_ds, V+1] back on the host (lib.py:640), decoded from there
             return [decoder.ids(torch.from_numpy(o).to(dev)) for o in outs]
@@ -451,15 +463,19 @@ def main():
     specs = [one_step(i) for i in range(a.warmup + a.steps)]
     if a.blank_bias < 0:  # shape the seeded model so pseudo-labels have a speech-like token rate (outside the timed region)
         from dynamic_asr_eval_amd.synthetic_weights import calibrate_blank_bias
+        model.active = 1                       # the calibration forwards one window through replica 0
         a.blank_bias = calibrate_blank_bias(model, specs[0][:, :, :a.seq_len].contiguous().to(dev))
+        model.active = R
     else:
         model.P["decoder.ff.bias"][-1] += a.blank_bias
+    if R > 1:
+        model.load_state_dict(model.state_dict())   # the calibrated blank bias into every replica
     for m in models[1:]:                       # every chain starts from the same weights
         m.flat_params.copy_(model.flat_params)
     if a.prewarm_s > 0:     # untimed, before the W warm-up steps: the workload itself, until the GPU has been under load for prewarm_s
         t_end = time.perf_counter() + a.prewarm_s
         while time.perf_counter() < t_end:
-            run_many(specs[:1] * n_chains)
+            run_many(specs[:1] * (n_chains * R))
     if a.warmup:
         run_many(specs[:a.warmup])              # W untimed steps (every chain's stream and workspace was already warmed by the prewarm)
     ddist.barrier()
@@ -484,7 +500,7 @@ def main():
     # side measurements on rank 0 at N = 1 (untimed as far as `value` goes): the model's own collapsing pseudo-labels, and the
     # boundary-faithful rate (host spectrogram in, numpy log-probs out, decoded from the host copy: reference lib.py:549,640)
     side = {}
-    n_side = n_chains if a.side_steps < 0 else a.side_steps
+    n_side = n_chains * R if a.side_steps < 0 else a.side_steps
     if world == 1 and n_side > 0:
         sl = specs[a.warmup:a.warmup + min(n_side, a.steps)]
         if a.label_tokens > 0:
@@ -513,7 +529,7 @@ def main():
                                    "6 freq masks <=34), SCConformerXL 6x768 V+1=4096 seeded weights",
                        "recording_seconds": a.seconds, "windows_per_recording": len(lib.prepare_chunks(specs[0], a.seq_len, a.overlap)[1]),
                        "sharding": f"{world} ranks x {a.steps} recordings, no data-path collective",
-                       "chains_per_gpu": n_chains, "hip_graphs": bool(a.graphs), "pcie_inclusive": bool(a.pcie), "prewarm_s": a.prewarm_s,
+                       "chains_per_gpu": n_chains, "lockstep_group": R, "hip_graphs": bool(a.graphs), "pcie_inclusive": bool(a.pcie), "prewarm_s": a.prewarm_s,
                        "blank_bias": round(a.blank_bias, 4), "hyp_tokens_per_recording": [len(h) for h in hyps]},
             "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -535,12 +551,16 @@ def main():
         }
         out.update(side)
         out["config"]["label_tokens_per_window"] = a.label_tokens
+        side_model = model
+        if R > 1 and world == 1 and (a.side_workloads or not a.no_cpu_baseline):   # the side legs drive one recording at a time: a plain model
+            side_model = SCConformerXL(vocab_size=a.vocab, device=dev)
+            side_model.load_state_dict(model.state_dict())
         if world == 1 and a.side_workloads:
-            out["other_workloads"] = other_workloads(a, model, dev)
+            out["other_workloads"] = other_workloads(a, side_model, dev)
         if world == 1 and not a.no_cpu_baseline:
-            for m in models:                                           # the parity leg runs on the bench's own (restored) weights
+            for m in models + [side_model]:                            # the parity leg runs on the bench's own (restored) weights
                 m.use_graphs = bool(a.graphs)
-            out["cpu_baseline"], out["parity"] = cpu_baseline(a, model, dev)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(a, side_model, dev)
         print(json.dumps(out), flush=True)
 
 

@@ -34,6 +34,7 @@ class GemmDesc(ctypes.Structure):
         ("a_colsum", ctypes.c_void_p),
         ("a_colsum_beta", ctypes.c_float), ("reserved3_", ctypes.c_float),
         ("counters", ctypes.c_void_p), ("n_counters", ctypes.c_int64),
+        ("bias_s1", ctypes.c_int64), ("bias_s2", ctypes.c_int64),
     ]
 
 

@@ -44,6 +44,7 @@ struct KParams {
     float* C; int64_t ldc, sc1, sc2;
     int64_t cin_delta;  // C_in - C in elements (0 = accumulate in place): beta reads the residual from another buffer
     const float* bias;
+    int64_t bs1, bs2;    // batch strides of the bias (0, 0: one bias for every batch; a weight-batched product has one bias row per weight)
     float alpha, beta;
     int64_t nb2;
     int splits;       // >= 1
@@ -487,7 +488,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #pragma unroll
             for (int b = 0; b < WTN; ++b) {
                 const int64_t col = n0 + wn * (BN / 2) + b * 32 + i;
-                const float bv = p.bias ? p.bias[col] : 0.f;
+                const float bv = p.bias ? p.bias[z1 * p.bs1 + z2 * p.bs2 + col] : 0.f;
                 float* cp = C + (m0 + wm * (BM / 2) + a * 32 + 4 * h) * p.ldc + col;
                 if (p.epi != 0) {             // activation fused into the store (host guarantees: no split / tail, aux set)
                     const int64_t ad = p.aux - p.C;
@@ -516,7 +517,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #pragma unroll
             for (int b = 0; b < WTN; ++b) {
                 const int64_t col = n0 + wn * (BN / 2) + b * 32 + i;
-                const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+                const float bv = (p.bias && col < p.N) ? p.bias[z1 * p.bs1 + z2 * p.bs2 + col] : 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t row = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -586,7 +587,7 @@ __global__ void splitk_reduce_kernel(const KParams p) {
         for (int k = 0; k < p.splits; ++k) s += p.ws[((int64_t)k * p.nbatch + zb) * mn + rem];
         const int64_t z1 = zb / p.nb2, z2 = zb % p.nb2;
         float* C = p.C + z1 * p.sc1 + z2 * p.sc2 + row * p.ldc + col;
-        float v = epi_value(p.alpha, s, p.beta, C + p.cin_delta, p.bias ? p.bias[col] : 0.f);
+        float v = epi_value(p.alpha, s, p.beta, C + p.cin_delta, p.bias ? p.bias[z1 * p.bs1 + z2 * p.bs2 + col] : 0.f);
         if (p.epi == 1) { if (p.aux) C[p.aux - p.C] = v; v = silu_f(v); }
         else if (p.epi == 2) v *= silu_grad_f(C[p.aux - p.C]);
         *C = v;
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(const KParams p, int B
         for (int j = 0; j < 4; ++j) {
             const int64_t col = col0 + j;
             if (col < p.N) {
-                float o = epi_value(p.alpha, v[j], p.beta, C + col + p.cin_delta, p.bias ? p.bias[col] : 0.f);
+                float o = epi_value(p.alpha, v[j], p.beta, C + col + p.cin_delta, p.bias ? p.bias[z1 * p.bs1 + z2 * p.bs2 + col] : 0.f);
                 if (p.epi == 1) { if (p.aux) C[col + (p.aux - p.C)] = o; o = silu_f(o); }
                 else if (p.epi == 2) o *= silu_grad_f(C[col + (p.aux - p.C)]);
                 C[col] = o;
@@ -779,7 +780,7 @@ extern "C" int dyn_gemm_f32(const dyn_gemm_desc* d, void* stream) {
     kp.A = d->A; kp.lda = d->lda; kp.sa1 = d->sa1; kp.sa2 = d->sa2;
     kp.B = d->B; kp.ldb = d->ldb; kp.sb1 = d->sb1; kp.sb2 = d->sb2;
     kp.C = d->C; kp.ldc = d->ldc; kp.sc1 = d->sc1; kp.sc2 = d->sc2;
-    kp.bias = d->bias; kp.alpha = d->alpha; kp.beta = d->beta;
+    kp.bias = d->bias; kp.bs1 = d->bias_s1; kp.bs2 = d->bias_s2; kp.alpha = d->alpha; kp.beta = d->beta;
     kp.cin_delta = d->C_in ? (int64_t)(d->C_in - d->C) : 0;
     kp.nb2 = d->nb2; kp.splits = pl.splits; kp.kchunk = pl.kchunk;
     kp.ws = (float*)d->workspace; kp.nbatch = batch;
@@ -870,7 +871,7 @@ extern "C" int dyn_gemm_f32_grouped(const dyn_gemm_desc* descs, int32_t n, void*
         kp.B = d->B; kp.ldb = d->ldb; kp.sb1 = 0; kp.sb2 = 0;
         kp.C = d->C; kp.ldc = d->ldc; kp.sc1 = 0; kp.sc2 = 0;
         kp.cin_delta = d->C_in ? (int64_t)(d->C_in - d->C) : 0;
-        kp.bias = nullptr; kp.alpha = d->alpha; kp.beta = d->beta;
+        kp.bias = nullptr; kp.bs1 = 0; kp.bs2 = 0; kp.alpha = d->alpha; kp.beta = d->beta;
         kp.nb2 = 1; kp.splits = 1; kp.kchunk = dyn::cdiv(d->K > 0 ? d->K : 1, BK) * BK;
         kp.ws = nullptr; kp.nbatch = 1;
         kp.tiles_m = (int)dyn::cdiv(d->M, BM); kp.tiles_n = (int)dyn::cdiv(d->N, BN);

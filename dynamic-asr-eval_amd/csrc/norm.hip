@@ -16,16 +16,23 @@ template <int NV, bool RMS>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                        int64_t rows, float eps) {
+                                                        int64_t rows, float eps, int64_t rps, int ngroups, int64_t pstride) {
+    // Lockstep groups (several recordings, each with its own adapted weights, in one batch): blockIdx.y = sample, a sample owns `rps`
+    // consecutive rows and takes the parameters of group (sample % ngroups) at gamma + group * pstride.  Ungrouped: gridDim.y = 1, rps = rows.
     constexpr int C = NV * 256;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t row_lo = (int64_t)blockIdx.y * rps;
+    const int64_t row_hi = row_lo + rps < rows ? row_lo + rps : rows;
+    const int64_t poff = (int64_t)(blockIdx.y % ngroups) * pstride;
+    gamma += poff;
+    if (!RMS && beta) beta += poff;
     float4 g[NV], b[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         g[j] = reinterpret_cast<const float4*>(gamma)[lane + 64 * j];
         b[j] = (!RMS && beta) ? reinterpret_cast<const float4*>(beta)[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int64_t row = (int64_t)blockIdx.x * WPB + w; row < rows; row += (int64_t)gridDim.x * WPB) {
+    for (int64_t row = row_lo + (int64_t)blockIdx.x * WPB + w; row < row_hi; row += (int64_t)gridDim.x * WPB) {
         float4 v[NV];
         float s = 0.f;
 #pragma unroll
@@ -71,10 +78,13 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
                                                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                         const float* __restrict__ dy, float* dx, float dx_beta,
                                                         float* __restrict__ partial_g, float* __restrict__ partial_b,
-                                                        int64_t rows, const float* dx_in) {
+                                                        int64_t rows, const float* dx_in, int64_t rps, int ngroups, int64_t pstride) {
     constexpr int C = NV * 256;
     __shared__ float4 red[WPB][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t row_lo = (int64_t)blockIdx.y * rps;                      // see norm_fwd_kernel: blockIdx.y = sample of a lockstep group
+    const int64_t row_hi = row_lo + rps < rows ? row_lo + rps : rows;
+    gamma += (int64_t)(blockIdx.y % ngroups) * pstride;
     float4 g[NV], ag[NV], ab[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -82,7 +92,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
         ag[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int64_t row = (int64_t)blockIdx.x * WPB + w; row < rows; row += (int64_t)gridDim.x * WPB) {
+    for (int64_t row = row_lo + (int64_t)blockIdx.x * WPB + w; row < row_hi; row += (int64_t)gridDim.x * WPB) {
         const float mean = RMS ? 0.f : mean_in[row];
         const float rstd = rstd_in[row];
         float4 xh[NV], gy[NV];
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
                 float4 t = red[0][lane];
 #pragma unroll
                 for (int k = 1; k < WPB; ++k) { t.x += red[k][lane].x; t.y += red[k][lane].y; t.z += red[k][lane].z; t.w += red[k][lane].w; }
-                float* dst = (pass == 0 ? partial_g : partial_b) + (int64_t)blockIdx.x * C;
+                float* dst = (pass == 0 ? partial_g : partial_b) + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * C;
                 reinterpret_cast<float4*>(dst)[lane + 64 * j] = t;
             }
         }
@@ -141,18 +151,24 @@ inline int bwd_blocks(int64_t rows) {
     return (int)g;
 }
 
+struct Grouping { int64_t rps; int n; int64_t pstride; };   // rows per sample, groups, parameter stride (elements); n <= 1: ungrouped
+
 template <bool RMS>
 int launch_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows,
-               int64_t C, float eps, hipStream_t st) {
-    int64_t gq = dyn::cdiv(rows, WPB);
+               int64_t C, float eps, hipStream_t st, Grouping gr = {0, 1, 0}) {
+    const bool grouped = gr.n > 1;
+    const int64_t rps = grouped ? gr.rps : rows;
+    const int ngroups = grouped ? gr.n : 1;
+    const int64_t pstride = grouped ? gr.pstride : 0;
+    int64_t gq = dyn::cdiv(rps, WPB);
     if (gq > 2048) gq = 2048;
-    dim3 grid((unsigned)gq), blk(256);
+    dim3 grid((unsigned)gq, grouped ? (unsigned)dyn::cdiv(rows, rps) : 1u), blk(256);
     switch (C / 256) {
-        case 1: hipLaunchKernelGGL((norm_fwd_kernel<1, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps); break;
-        case 2: hipLaunchKernelGGL((norm_fwd_kernel<2, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps); break;
-        case 3: hipLaunchKernelGGL((norm_fwd_kernel<3, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps); break;
-        case 4: hipLaunchKernelGGL((norm_fwd_kernel<4, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps); break;
-        case 8: hipLaunchKernelGGL((norm_fwd_kernel<8, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps); break;
+        case 1: hipLaunchKernelGGL((norm_fwd_kernel<1, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps, rps, ngroups, pstride); break;
+        case 2: hipLaunchKernelGGL((norm_fwd_kernel<2, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps, rps, ngroups, pstride); break;
+        case 3: hipLaunchKernelGGL((norm_fwd_kernel<3, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps, rps, ngroups, pstride); break;
+        case 4: hipLaunchKernelGGL((norm_fwd_kernel<4, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps, rps, ngroups, pstride); break;
+        case 8: hipLaunchKernelGGL((norm_fwd_kernel<8, RMS>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, eps, rps, ngroups, pstride); break;
         default: dyn::set_error("norm: unsupported C=%lld (need C in {256,512,768,1024,2048})", (long long)C); return DYN_E_UNSUPPORTED;
     }
     return dyn::check_launch("dyn_norm_fwd");
@@ -161,25 +177,38 @@ int launch_fwd(const float* x, const float* gamma, const float* beta, float* y, 
 template <bool RMS>
 int launch_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
                float dx_beta, float* dgamma, float* dbeta, float wbeta, int64_t rows, int64_t C, void* ws, int64_t ws_bytes,
-               hipStream_t st, const float* dx_in = nullptr) {
+               hipStream_t st, const float* dx_in = nullptr, Grouping gr = {0, 1, 0}) {
     if (dx_in == nullptr) dx_in = dx;
-    const int nb = bwd_blocks(rows);
+    const bool grouped = gr.n > 1;
+    const int64_t rps = grouped ? gr.rps : rows;
+    const int ngroups = grouped ? gr.n : 1;
+    const int64_t pstride = grouped ? gr.pstride : 0;
+    const int nsamp = grouped ? (int)dyn::cdiv(rows, rps) : 1;
+    const int nbs = bwd_blocks(rps);            // workgroups (= partial rows) per sample
+    const int nb = nbs * nsamp;
     DYN_REQUIRE(ws && ws_bytes >= (int64_t)2 * nb * C * (int64_t)sizeof(float), DYN_E_WORKSPACE, "norm_bwd: workspace too small");
     float* pg = dyn::partials_alloc(ws, (int64_t)2 * nb * C * (int64_t)sizeof(float));   // the workspace, or the open deferral context's arena
     float* pb = pg + (int64_t)nb * C;
-    dim3 grid(nb), blk(256);
+    dim3 grid(nbs, nsamp), blk(256);
     switch (C / 256) {
-        case 1: hipLaunchKernelGGL((norm_bwd_kernel<1, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in); break;
-        case 2: hipLaunchKernelGGL((norm_bwd_kernel<2, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in); break;
-        case 3: hipLaunchKernelGGL((norm_bwd_kernel<3, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in); break;
-        case 4: hipLaunchKernelGGL((norm_bwd_kernel<4, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in); break;
-        case 8: hipLaunchKernelGGL((norm_bwd_kernel<8, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in); break;
+        case 1: hipLaunchKernelGGL((norm_bwd_kernel<1, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in, rps, ngroups, pstride); break;
+        case 2: hipLaunchKernelGGL((norm_bwd_kernel<2, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in, rps, ngroups, pstride); break;
+        case 3: hipLaunchKernelGGL((norm_bwd_kernel<3, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in, rps, ngroups, pstride); break;
+        case 4: hipLaunchKernelGGL((norm_bwd_kernel<4, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in, rps, ngroups, pstride); break;
+        case 8: hipLaunchKernelGGL((norm_bwd_kernel<8, RMS>), grid, blk, 0, st, x, gamma, mean, rstd, dy, dx, dx_beta, pg, pb, rows, dx_in, rps, ngroups, pstride); break;
         default: dyn::set_error("norm: unsupported C=%lld", (long long)C); return DYN_E_UNSUPPORTED;
     }
-    if (!RMS && dgamma && dbeta) dyn::reduce_pair_or_defer(pg, dgamma, pb, dbeta, (int64_t)nb, C, wbeta, st);
-    else {
-        if (dgamma) dyn::reduce_or_defer(pg, dgamma, (int64_t)nb, C, wbeta, st);
-        if (!RMS && dbeta) dyn::reduce_or_defer(pb, dbeta, (int64_t)nb, C, wbeta, st);
+    // one reduction per sample into its group's gradient; a group's second sample accumulates onto the first (recording order = sample order)
+    for (int sidx = 0; sidx < nsamp; ++sidx) {
+        const int64_t po = (int64_t)(sidx % ngroups) * pstride;
+        const float wb = sidx < ngroups ? wbeta : 1.f;
+        float* pgs = pg + (int64_t)sidx * nbs * C;
+        float* pbs = pb + (int64_t)sidx * nbs * C;
+        if (!RMS && dgamma && dbeta) dyn::reduce_pair_or_defer(pgs, dgamma + po, pbs, dbeta + po, (int64_t)nbs, C, wb, st);
+        else {
+            if (dgamma) dyn::reduce_or_defer(pgs, dgamma + po, (int64_t)nbs, C, wb, st);
+            if (!RMS && dbeta) dyn::reduce_or_defer(pbs, dbeta + po, (int64_t)nbs, C, wb, st);
+        }
     }
     return dyn::check_launch("dyn_norm_bwd");
 }
@@ -257,6 +286,46 @@ extern "C" int dyn_chanaffine_bwd(const float* x, const float* mean, const float
 
 extern "C" int64_t dyn_norm_bwd_workspace_bytes(int64_t rows, int64_t C) {
     return (int64_t)2 * bwd_blocks(rows) * C * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t dyn_norm_bwd_workspace_bytes_g(int64_t rows, int64_t C, int64_t rows_per_sample) {
+    const int64_t rps = rows_per_sample > 0 ? rows_per_sample : rows;
+    return (int64_t)2 * bwd_blocks(rps) * dyn::cdiv(rows, rps > 0 ? rps : 1) * C * (int64_t)sizeof(float);
+}
+
+// ---- lockstep-group variants: `rows` = n_samples * rows_per_sample rows; sample s uses the parameters of group s % n_groups, stored
+// param_stride elements apart (the flat parameter buffers of the group's model replicas); weight gradients go to dgamma + group * param_stride.
+extern "C" int dyn_layernorm_fwd_g(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                   int64_t rows, int64_t C, float eps, int64_t rows_per_sample, int64_t n_groups, int64_t param_stride,
+                                   void* stream) {
+    DYN_REQUIRE(x && gamma && y && mean && rstd && rows >= 0 && C > 0 && C % 256 == 0 && rows_per_sample > 0 && n_groups >= 1 &&
+                    rows % rows_per_sample == 0 && (rows / rows_per_sample) % n_groups == 0 && param_stride % 4 == 0,
+                DYN_E_ARG, "dyn_layernorm_fwd_g: bad arguments");
+    if (rows == 0) return DYN_OK;
+    return launch_fwd<false>(x, gamma, beta, y, mean, rstd, rows, C, eps, (hipStream_t)stream, Grouping{rows_per_sample, (int)n_groups, param_stride});
+}
+
+extern "C" int dyn_layernorm_bwd_g(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy,
+                                   const float* dx_in, float* dx, float dx_beta, float* dgamma, float* dbeta, float wgrad_beta,
+                                   int64_t rows, int64_t C, int64_t rows_per_sample, int64_t n_groups, int64_t param_stride,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+    DYN_REQUIRE(x && gamma && mean && rstd && dy && dx && rows >= 0 && C > 0 && C % 256 == 0 && rows_per_sample > 0 && n_groups >= 1 &&
+                    rows % rows_per_sample == 0 && (rows / rows_per_sample) % n_groups == 0 && param_stride % 4 == 0,
+                DYN_E_ARG, "dyn_layernorm_bwd_g: bad arguments");
+    if (rows == 0) return DYN_OK;
+    return launch_bwd<false>(x, gamma, mean, rstd, dy, dx, dx_beta, dgamma, dbeta, wgrad_beta, rows, C, workspace, workspace_bytes,
+                             (hipStream_t)stream, dx_in, Grouping{rows_per_sample, (int)n_groups, param_stride});
+}
+
+extern "C" int dyn_rmsnorm_bwd_g(const float* x, const float* gamma, const float* rstd, const float* dy, float* dx, float dx_beta,
+                                 float* dgamma, float wgrad_beta, int64_t rows, int64_t C, int64_t rows_per_sample, int64_t n_groups,
+                                 int64_t param_stride, void* workspace, int64_t workspace_bytes, void* stream) {
+    DYN_REQUIRE(x && gamma && rstd && dy && dx && rows >= 0 && C > 0 && C % 256 == 0 && rows_per_sample > 0 && n_groups >= 1 &&
+                    rows % rows_per_sample == 0 && (rows / rows_per_sample) % n_groups == 0 && param_stride % 4 == 0,
+                DYN_E_ARG, "dyn_rmsnorm_bwd_g: bad arguments");
+    if (rows == 0) return DYN_OK;
+    return launch_bwd<true>(x, gamma, nullptr, rstd, dy, dx, dx_beta, dgamma, nullptr, wgrad_beta, rows, C, workspace, workspace_bytes,
+                            (hipStream_t)stream, nullptr, Grouping{rows_per_sample, (int)n_groups, param_stride});
 }
 
 extern "C" int dyn_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

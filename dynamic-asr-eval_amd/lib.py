@@ -446,6 +446,210 @@ def _dynamic_eval_gen(
     return logits if not return_params else (logits, updated_model_params)
 
 
+def lockstep_supported(args, model, specs, beam_search_fn=None, optimizer_state=None):
+    """Can `specs` go through ONE lockstep group of `model` (SCConformerXL(group=R))?  The group form covers the standard recipe (SpecAugment
+    on copy 0, MADGRAD / Adam, online or final pass, epochs, shuffle); the optional augmentations, optimiser state hand-over, LM beam search
+    and recordings of different lengths keep the one-recording-per-chain path."""
+    a = args.__dict__
+    if not (_is_native(model) and getattr(model, "R", 1) > 1 and 1 <= len(specs) <= model.R):
+        return False
+    if beam_search_fn is not None or optimizer_state is not None:
+        return False
+    if a.get('random_noise', 0.0) or any(a.get(k, False) for k in ('freeze_subsampling', 'freeze_all_but_last_block_and_head', 'train_subsampling_only')):
+        return False
+    if any(v for v in get_frame_shuffle_config_from_args(args).values()) or a.get('cutout_num_rectangles', 0) or a.get('entropy_augmentation_enabled', False):
+        return False
+    if not a.get('skip_zero_grad_samples', True):
+        return False
+    return len({int(sp.shape[-1]) for sp in specs}) == 1
+
+
+def _dynamic_eval_group_gen(args, model, specs, seq_len, overlap, tokenizer, use_tqdm=True, optim=MADGRAD, optimizer_state=None,
+                            beam_search_fn=None, return_params=False, return_device=False):
+    """dynamic_eval_ctc_loss (reference lcasr/lib.py:450-640) for R' = len(specs) recordings of EQUAL length in lockstep on one
+    SCConformerXL(group=R >= R'): every window step runs ONCE for all of them — batch [2 R', F, T] ordered (augmented copies of recordings
+    0 .. R'-1, then their clean copies), one forward, one greedy decode, one CTC launch over the R' augmented copies (each recording's loss
+    and gradient scaled as if it were alone: reduction 'sum', 1 / (N * B) with B = 1), one backward on the R' augmented samples, one
+    optimiser launch over the [R', n_flat] buffers.  Recordings stay independent (own weights, own optimiser state, own stitch buffers):
+    per recording the results are those of `dynamic_eval` up to the GEMM planner's choice of tile for the larger launches.
+    Generator with the same yield points as _dynamic_eval_gen; returns the list of per-recording results in StopIteration.value."""
+    if not lockstep_supported(args, model, specs, beam_search_fn, optimizer_state):
+        raise ops.DynError("dynamic_eval lockstep group: unsupported configuration (see lockstep_supported)")
+    device = model.device
+    Rn = len(specs)
+    spec_n = specs[0].shape[-1]
+    downsampling_factor = args.config['model']['subsampling_factor']
+    seq_len = seq_len if seq_len != -1 else args.config['audio_chunking']['size']
+    spec_augment_config = get_specaugment_config_from_args(args)
+    lr_args = get_lr_args_from_args(args)
+    num_negatives = 1
+    prev_active = model.active
+    model.active = Rn
+    n_flat = model.n_flat
+    original_flat = model.flat_params[:Rn * n_flat].clone()
+    num_classes = model.decoder.num_classes
+    blank = num_classes - 1
+    optimizer = optim(model.parameters(), **lr_args)             # flat [R', n_flat] buffers: one launch per step for the whole group
+    augmentation = SpecAugment(**spec_augment_config)
+    fixed_masks = args.__dict__.get('spec_augment_fixed_masks', None)  # test hook: {window_key: masks} or one such dict per recording
+    if seq_len > spec_n:
+        seq_len, overlap = spec_n, 0
+    else:
+        overlap = overlap if overlap != -1 else args.config['audio_chunking']['overlap']
+    assert args.config['training'].get("max_seq_len", 0) == 0, 'caching is not used anymore'
+    assert overlap / downsampling_factor == overlap // downsampling_factor, 'Overlap must be a multiple of the downsampling factor'
+    assert tokenizer.vocab_size() + 1 == num_classes, 'tokenizer vocabulary does not match the CTC head'
+    epochs = args.__dict__.get('epochs', 1)
+    shuffle = args.__dict__.get('shuffle', False)
+    online = args.__dict__.get('online', False)
+    shuffle = False if online else shuffle
+    final_batch = max(1, int(args.__dict__.get('final_pass_batch', 4)))
+    specs_dev = [sp.to(device=device, dtype=torch.float32) for sp in specs]
+    for sp in specs_dev:
+        if sp.dim() != 3 or sp.shape[0] != 1:
+            raise ops.DynError(f"spec must be [1, F, T], got {tuple(sp.shape)}")
+    Fq = specs_dev[0].shape[1]
+    acc_rows = spec_n // 4 + seq_len
+    acc = [torch.zeros(acc_rows, num_classes, device=device, dtype=torch.float32) for _ in range(Rn)]
+    cnt = [torch.zeros(acc_rows, device=device, dtype=torch.float32) for _ in range(Rn)]
+    stitch = [{"pos": 0, "end": 0} for _ in range(Rn)]
+
+    def stitch_window(r, key, log_probs_2d, u_len):
+        ds_len = log_probs_2d.shape[0]
+        overlap_ds = int(overlap / (u_len / ds_len))
+        st = stitch[r]
+        st["pos"] -= overlap_ds if key != 0 else 0
+        ops.stitch_accumulate(log_probs_2d, acc[r], cnt[r], st["pos"])
+        st["pos"] += ds_len
+        st["end"] = max(st["end"], st["pos"])
+
+    model.use_graphs = bool(args.__dict__.get('use_graphs', True))
+    model.grad_samples = num_negatives * Rn if _CLEAN_COPY_FUSED_ATTN else None
+    model.eval()
+    data = [prepare_chunks(sp, seq_len, overlap)[0] for sp in specs_dev]
+    pinned = None
+    tgt_ring, tgt_turn = None, 0
+    try:
+        for epoch in range(args.__dict__.get('epochs', 1)):
+            if online and epoch > 0:
+                for r in range(Rn):
+                    acc[r].zero_(); cnt[r].zero_()
+                    stitch[r]["pos"] = stitch[r]["end"] = 0
+            training_keys = list(data[0].keys())
+            training_keys = random.sample(training_keys, len(training_keys)) if shuffle else training_keys
+            for i in (tqdm(training_keys) if use_tqdm else training_keys):
+                sampled = 0
+                if ops.gemm_profile_active():
+                    sampled = ops.gemm_profile_begin_step(device)
+                u_len = data[0][i].shape[-1]
+                audio_chunk = torch.empty(2 * Rn, Fq, u_len, device=device, dtype=torch.float32)
+                for r in range(Rn):
+                    view = data[r][i][0]
+                    audio_chunk[r].copy_(view)
+                    audio_chunk[Rn + r].copy_(view)
+                    fm = fixed_masks[r] if isinstance(fixed_masks, (list, tuple)) else fixed_masks
+                    masks = fm[i] if fm is not None else augmentation.draw(Fq, u_len)
+                    if masks[0][0] or masks[1][0]:
+                        augmentation.apply(audio_chunk[r], masks, _window_fill_value(audio_chunk[r], augmentation.zero_masking))
+                with torch.enable_grad():
+                    post = model(audio_signal=audio_chunk)['final_posteriors']     # [2 R', N, C]
+                ids_dev, n_dev = ops.ctc_greedy(post[Rn:].detach(), blank)       # pseudo-labels of the clean copies
+                if pinned is None or pinned[0].shape[1] < ids_dev.shape[1]:
+                    pinned = (torch.empty(Rn, ids_dev.shape[1], dtype=torch.int32, pin_memory=True), torch.empty(Rn, dtype=torch.int32, pin_memory=True))
+                pinned[0][:, :ids_dev.shape[1]].copy_(ids_dev, non_blocking=True)
+                pinned[1].copy_(n_dev, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record()
+                if sampled:
+                    ops.gemm_profile_before_yield(sampled, ready)
+                yield
+                _t0 = time.perf_counter()
+                if ops.gemm_profile_active():
+                    ops.gemm_profile_resume_step(device, sampled)
+                ready.synchronize()
+                HOST_WAIT[0] += time.perf_counter() - _t0
+                target_ids = []
+                for r in range(Rn):
+                    pseudo_targets = tokenizer.decode(pinned[0][r, :int(pinned[1][r])].tolist())
+                    target_ids.append(tokenizer.encode(pseudo_targets))                   # text hop kept (reference lib.py:569)
+                S_max = max(1, max(len(t) for t in target_ids))
+                if tgt_ring is None or tgt_ring[0].shape[1] < S_max:
+                    tgt_ring = [torch.zeros(Rn, max(2 * S_max, 256), dtype=torch.int32, pin_memory=True) for _ in range(4)]
+                slot = tgt_ring[tgt_turn % 4]
+                lens = tgt_ring_len = torch.empty(Rn, dtype=torch.int32, pin_memory=True)
+                tgt_turn += 1
+                for r, t in enumerate(target_ids):
+                    if t:
+                        slot[r, :len(t)] = torch.as_tensor(t, dtype=torch.int32)
+                    lens[r] = len(t)
+                targets = torch.empty(Rn, S_max, dtype=torch.int32, device=device)
+                targets.copy_(slot[:, :S_max], non_blocking=True)
+                tlen = torch.empty(Rn, dtype=torch.int32, device=device)
+                tlen.copy_(tgt_ring_len, non_blocking=True)
+                N = post.shape[1]
+                ilen = torch.full((Rn,), N, dtype=torch.int32, device=device)
+                # per recording: CTCLoss(reduction='sum') / (N * B) with B = num_negatives = 1 (reference lib.py:572-575); 'sum' over the
+                # group's samples leaves every sample its own gradient
+                _, _, g_aug = ops.ctc_loss(post[:Rn].contiguous(), targets, ilen, tlen, blank, reduction="sum", grad_scale=1.0 / (N * num_negatives))
+                optimizer.zero_grad()
+                model.backward(g_aug, n_active=Rn)
+                optimizer.step()
+                if online:
+                    for r in range(Rn):
+                        stitch_window(r, i, post[Rn + r].detach(), u_len)
+                if sampled:
+                    ops.gemm_profile_end_step(device, sampled)
+        if not online:
+            model.eval()
+            keys = sorted(data[0].keys())
+            idx = 0
+            while idx < len(keys):
+                group = [keys[idx]]
+                u_len = data[0][keys[idx]].shape[-1]
+                while len(group) < final_batch and idx + len(group) < len(keys) and data[0][keys[idx + len(group)]].shape[-1] == u_len:
+                    group.append(keys[idx + len(group)])
+                sampled = 0
+                if ops.gemm_profile_active():
+                    sampled = ops.gemm_profile_begin_step(device)
+                batch = torch.empty(len(group) * Rn, Fq, u_len, device=device, dtype=torch.float32)
+                for c, k in enumerate(group):
+                    for r in range(Rn):
+                        batch[c * Rn + r].copy_(data[r][k][0])
+                with torch.no_grad():
+                    post = model(audio_signal=batch)['final_posteriors']
+                    for c, k in enumerate(group):
+                        for r in range(Rn):
+                            stitch_window(r, k, post[c * Rn + r], u_len)
+                idx += len(group)
+                if sampled:
+                    ops.gemm_profile_end_step(device, sampled)
+                yield
+            model.train()
+        results = []
+        for r in range(Rn):
+            logits_dev = ops.stitch_finalize(acc[r], cnt[r], stitch[r]["end"])
+            logits = logits_dev if return_device else logits_dev.cpu().numpy()
+            if return_params:
+                results.append((logits, [p.clone().detach().cpu() for p in model.replica_params(r)]))
+            else:
+                results.append(logits)
+    finally:
+        model.flat_params[:Rn * n_flat].copy_(original_flat)      # reference lib.py:636-637
+        model.grad_samples = None
+        model.active = prev_active
+    return results
+
+
+def dynamic_eval_lockstep(args, model, specs, seq_len, overlap, tokenizer, **kw):
+    """`specs` (<= model.R recordings of equal length) through one lockstep group; list of per-recording results (see _dynamic_eval_group_gen)."""
+    gen = _dynamic_eval_group_gen(args, model, specs, seq_len, overlap, tokenizer, **kw)
+    try:
+        while True:
+            next(gen)
+    except StopIteration as stop:
+        return stop.value
+
+
 def dynamic_eval_ctc_loss(args, model, spec, seq_len, overlap, tokenizer, use_tqdm=True, optim=MADGRAD, optimizer_state=None,
                           beam_search_fn=None, return_params=False, return_device=False):
     """Reference lcasr/lib.py:450-640.  Returns np.float32 [T_ds, V+1] log-probs (and the adapted parameters as CPU
@@ -521,6 +725,20 @@ def dynamic_eval_many(args, models, specs, seq_len, overlap, tokenizer, **kw):
             if k:
                 check(load().dyn_sleep_us(min(k * stagger_us, 2000000), st.cuda_stream), "dyn_sleep_us")
     pending = list(enumerate(specs))
+    R = getattr(models[0], "R", 1)
+    if R > 1:
+        # lockstep groups: consecutive recordings of equal length share one group model (up to R at a time); what the group form does not
+        # cover (lockstep_supported) cannot run on a group model at all, so it is refused here rather than silently run differently
+        items, k = [], 0
+        while k < len(specs):
+            n = 1
+            while n < R and k + n < len(specs) and specs[k + n].shape[-1] == specs[k].shape[-1]:
+                n += 1
+            if not lockstep_supported(args, models[0], specs[k:k + n], kw.get('beam_search_fn'), kw.get('optimizer_state')):
+                raise ops.DynError("dynamic_eval_many: these arguments need the one-recording-per-model path (pass ungrouped models)")
+            items.append((list(range(k, k + n)), specs[k:k + n]))
+            k += n
+        pending = items
     results = [None] * len(specs)
     free, active = list(range(len(models)))[::-1], []
     try:
@@ -538,14 +756,21 @@ def _run_chains(args, models, streams, pending, results, free, active, seq_len, 
         while pending and free:
             ci = free.pop()
             idx, spec = pending.pop(0)
-            active.append([_dynamic_eval_gen(args, models[ci], spec, seq_len, overlap, tokenizer, **kw), ci, idx])
+            if isinstance(idx, list):     # a lockstep group of recordings on a group model
+                active.append([_dynamic_eval_group_gen(args, models[ci], spec, seq_len, overlap, tokenizer, **kw), ci, idx])
+            else:
+                active.append([_dynamic_eval_gen(args, models[ci], spec, seq_len, overlap, tokenizer, **kw), ci, idx])
         for item in list(active):
             gen, ci, idx = item
             with torch.cuda.stream(streams[ci]):
                 try:
                     next(gen)
                 except StopIteration as stop:
-                    results[idx] = stop.value
+                    if isinstance(idx, list):
+                        for j, res in zip(idx, stop.value):
+                            results[j] = res
+                    else:
+                        results[idx] = stop.value
                     active.remove(item)
                     free.append(ci)
 

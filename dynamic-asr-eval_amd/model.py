@@ -131,10 +131,20 @@ class _Group:
 
 
 class SCConformerXL:
-    def __init__(self, config=None, vocab_size=128, device="cuda:0", extra_spec=None):
+    def __init__(self, config=None, vocab_size=128, device="cuda:0", extra_spec=None, group=1):
         """`extra_spec`: [(name, shape)] of further parameters placed in the SAME flat buffers (the enc-dec model appends its
-        decoder there, so snapshot / restore / optimiser step stay single operations)."""
+        decoder there, so snapshot / restore / optimiser step stay single operations).
+        `group` = R > 1: a LOCKSTEP GROUP of R model replicas in one object: parameters, gradients and optimiser state are
+        [R, n_flat] buffers, a batch holds `chunks * R` samples ordered sample = chunk * R + replica, and every launch covers all R
+        recordings — each linear layer one product batched over the replicas' weights, every parameter-free row-wise kernel one launch over
+        all samples, LayerNorm / RMSNorm one launch with a per-sample parameter offset; the few kernels without a group form (fused conv
+        module, depthwise convolutions, fused subsampling) run once per sample.  Per replica the arithmetic is that of a single model
+        (tests/test_model_gpu.py::test_lockstep_group_matches_separate_models)."""
         self.config = make_config(**(config or {}))
+        self.R = int(group)
+        if self.R < 1:
+            raise ValueError("group must be >= 1")
+        self.active = self.R        # replicas taking part in the current batches (a last, smaller group of recordings uses the first `active`)
         cfg = self.config
         if cfg["conv_norm"] not in ("rms_norm", "layer_norm", "batch_renorm"):
             raise ValueError(f"unknown conv_norm {cfg['conv_norm']}")
@@ -151,12 +161,17 @@ class SCConformerXL:
             self._slots[name] = (off, n, shape)
             off += (n + 63) // 64 * 64
         self.n_flat = off
-        self.flat_params = torch.zeros(off, device=self.device, dtype=torch.float32)
-        self.flat_grads = torch.zeros(off, device=self.device, dtype=torch.float32)
-        self.P, self.G = {}, {}
+        R = self.R
+        self.flat_params = torch.zeros(R * off, device=self.device, dtype=torch.float32)
+        self.flat_grads = torch.zeros(R * off, device=self.device, dtype=torch.float32)
+        self.P, self.G = {}, {}          # replica 0's views (the whole model when R == 1)
+        self.PR, self.GR = {}, {}        # [R, *shape] views over the group
+        fp, fg = self.flat_params.view(R, off), self.flat_grads.view(R, off)
         for name, (o, n, shape) in self._slots.items():
             self.P[name] = self.flat_params[o:o + n].view(shape)
             self.G[name] = self.flat_grads[o:o + n].view(shape)
+            self.PR[name] = fp[:, o:o + n].view(R, *shape)
+            self.GR[name] = fg[:, o:o + n].view(R, *shape)
         self.buffers = {}
         if cfg["conv_norm"] == "batch_renorm":
             for l in range(cfg["n_layers"]):
@@ -202,13 +217,29 @@ class SCConformerXL:
         self.fused_attention_grad = _parse_fused_attn_grad(os.environ.get("DYN_FUSED_ATTN_GRAD", "4096"))
         self.training = False
 
+    # ------------------------------------------------------------------ lockstep group helpers
+    def _w(self, name):
+        """The parameter as the kernels take it: the tensor itself, or (R > 1) the group view with its replica stride."""
+        return self.P[name] if self.R == 1 else ops.GroupParam(self.PR[name][:self.active], self.active, self.n_flat)
+
+    def _gw(self, name):
+        return self.G[name] if self.R == 1 else ops.GroupParam(self.GR[name][:self.active], self.active, self.n_flat)
+
+    def replica_params(self, r):
+        """Views of replica r's parameters, in named_parameters() order."""
+        return [self.PR[n][r] for n, _ in self.spec]
+
+    def replica_flat(self, r):
+        return self.flat_params.view(self.R, self.n_flat)[r]
+
     # ------------------------------------------------------------------ nn.Module-like surface
     def named_parameters(self):
         return [(n, self.P[n]) for n, _ in self.spec]
 
     def parameters(self):
         pl = ParamList(self.P[n] for n, _ in self.spec)
-        pl.flat_params, pl.flat_grads = self.flat_params, self.flat_grads
+        n = self.active * self.n_flat         # a lockstep group steps its active replicas' buffers in one launch
+        pl.flat_params, pl.flat_grads = self.flat_params[:n], self.flat_grads[:n]
         return pl
 
     def grads(self):
@@ -226,7 +257,9 @@ class SCConformerXL:
             raise KeyError(f"missing {missing[:5]}… unexpected {unexpected[:5]}…")
         for n, _ in self.spec:
             if n in sd:
-                self.P[n].copy_(sd[n].to(self.device, torch.float32).reshape(self.P[n].shape))
+                src = sd[n].to(self.device, torch.float32).reshape(self.P[n].shape)
+                for r in range(self.R):          # every replica of a lockstep group starts from the same weights
+                    self.PR[n][r].copy_(src)
         for n in self.buffers:
             if n in sd:
                 self.buffers[n].copy_(sd[n].to(self.device, torch.float32))
@@ -270,6 +303,8 @@ class SCConformerXL:
         must then stay unmodified until the queue is flushed (the residual-stream gradient gets a new buffer per module)."""
         wg = self.trainable(wname) and not self._skip_wgrad
         bg = bname is not None and self.trainable(bname) and not self._skip_wgrad   # bitfit trains a bias under a frozen weight
+        if self.R > 1:
+            return self._lin_bwd_group(dy, x, wname, bname, wg, bg, need_dx, alpha, silu_of)
         if wg and self._wq is not None and (wname.startswith("layers.") or wname == "subsampling.out.weight") \
                 and ops.wgrad_groupable(dy, x, self.G[wname]):
             self._wq.append(ops.wgrad_desc(dy, x, self.G[wname], alpha=alpha, beta=1.0, colsum=self.G[bname] if bg else None, colsum_beta=1.0))
@@ -301,6 +336,43 @@ class SCConformerXL:
         dx = ops.linear_dgrad(dy, self.P[wname], alpha=alpha)
         return ops.silu_bwd(silu_of, dx, out=dx) if silu_of is not None else dx
 
+    def _lin_bwd_group(self, dy, x, wname, bname, wg, bg, need_dx, alpha, silu_of):
+        """_lin_bwd over a lockstep group (the backward batch holds ONE chunk: sample r = replica r): every replica's weight gradient is its
+        own descriptor of the grouped launch (its rows of dy and x are contiguous), the input gradient one product batched over the weights."""
+        R = self.active
+        if dy.shape[0] != R:
+            raise ops.DynError(f"lockstep group: the backward runs on one sample per replica (got a batch of {dy.shape[0]} for {R} replicas)")
+        GR = self.GR
+        shared = wname in ("decoder.ff.weight", "decoder.reproj.weight") and self.stack_shared_wgrads and alpha == 1.0
+        block_local = wname.startswith("layers.") or wname == "subsampling.out.weight"      # the deep-K subsampling products stay immediate (split-K)
+        if wg and self._wq is not None and (block_local or shared) and ops.wgrad_groupable(dy[0], x[0], GR[wname][0]):
+            for r in range(R):
+                if shared:      # one slab per use and replica, summed in use order after the grouped launch (see _lin_bwd)
+                    sh = self._shared.get((wname, r))
+                    if sh is None:
+                        cap = self.config["n_layers"] + 1
+                        sh = {"w": torch.empty(cap, *GR[wname][r].shape, device=self.device, dtype=torch.float32),
+                              "b": torch.empty(cap, GR[bname][r].numel(), device=self.device, dtype=torch.float32) if bg else None, "bname": bname, "k": 0,
+                              "wname": wname, "r": r}
+                        self._shared[(wname, r)] = sh
+                    k = sh["k"]
+                    sh["k"] = k + 1
+                    self._wq.append(ops.wgrad_desc(dy[r], x[r], sh["w"][k], alpha=1.0, beta=0.0, colsum=sh["b"][k] if sh["b"] is not None else None,
+                                                   colsum_beta=0.0))
+                else:
+                    self._wq.append(ops.wgrad_desc(dy[r], x[r], GR[wname][r], alpha=alpha, beta=1.0, colsum=GR[bname][r] if bg else None, colsum_beta=1.0))
+            bg = False
+        elif wg:
+            for r in range(R):
+                ops.linear_wgrad(dy[r], x[r], GR[wname][r], alpha=alpha, beta=1.0)
+        if bg:
+            for r in range(R):
+                ops.colsum(dy[r], GR[bname][r], beta=1.0)
+        if not need_dx:
+            return None
+        dx = ops.linear_dgrad(dy, self._w(wname), alpha=alpha)
+        return ops.silu_bwd(silu_of, dx, out=dx) if silu_of is not None else dx
+
     def _check_not_queued(self, t, what):
         """An in-place update of `t` while a queued weight-gradient descriptor still reads it would corrupt that gradient (the
         descriptors hold raw pointers until the flush at the end of the backward): refuse instead of computing garbage."""
@@ -314,10 +386,10 @@ class SCConformerXL:
     def _res_norm_bwd(self, h, wn, bn_, mean, rstd, dn, dh):
         """dh_out = dh + LayerNorm_bwd(dn): in place, or into a NEW buffer while weight gradients that read dh are still queued."""
         if self._wq is None:
-            ops.layernorm_bwd(h, self.P[wn], mean, rstd, dn, dh, self.G[wn], self.G[bn_], dx_beta=1.0)
+            ops.layernorm_bwd(h, self._w(wn), mean, rstd, dn, dh, self._gw(wn), self._gw(bn_), dx_beta=1.0)
             return dh
         out = torch.empty_like(dh)
-        ops.layernorm_bwd(h, self.P[wn], mean, rstd, dn, out, self.G[wn], self.G[bn_], dx_beta=1.0, dx_in=dh)
+        ops.layernorm_bwd(h, self._w(wn), mean, rstd, dn, out, self._gw(wn), self._gw(bn_), dx_beta=1.0, dx_in=dh)
         return out
 
     # ------------------------------------------------------------------ forward
@@ -326,10 +398,10 @@ class SCConformerXL:
 
     def _scratch(self):
         if self._ws is None:
-            self._ws = torch.empty(ops.WORKSPACE_BYTES, dtype=torch.uint8, device=self.device)
+            self._ws = torch.empty(ops.WORKSPACE_BYTES * self.R, dtype=torch.uint8, device=self.device)
             ops.counters(self._ws)          # zeroed arrival counters of this replica's GEMMs, allocated outside any graph capture
             if self.defer_reduces:          # partial sums of the backward's deferred column reductions (ops.reduce_defer)
-                self._defer_arena = torch.empty(ops.DEFER_ARENA_BYTES, dtype=torch.uint8, device=self.device)
+                self._defer_arena = torch.empty(ops.DEFER_ARENA_BYTES * self.R, dtype=torch.uint8, device=self.device)
         return self._ws
 
     def forward(self, audio_signal):
@@ -350,7 +422,7 @@ class SCConformerXL:
             return self._forward_eager(x)
         G = self._graphs
         key = (tuple(x.shape), torch.is_grad_enabled(), self.fused_convmod, self.fused_attention, self.fused_silu, str(self.fused_attention_grad),
-               self.fused_subsampling, self.grad_samples)
+               self.fused_subsampling, self.grad_samples, self.active)
         ent = G["fwd"].get(key)
         if ent is None:
             G["seen"][key] = G["seen"].get(key, 0) + 1
@@ -379,7 +451,10 @@ class SCConformerXL:
         return ent["out"]
 
     def _forward_eager(self, x):
-        cfg, P = self.config, self.P
+        cfg, P, W, R = self.config, self.P, self._w, (self.active if self.R > 1 else 1)
+        if self.R > 1 and (x.shape[0] % R or not self.fused_subsampling or not self.fused_convmod or self.fused_silu or cfg["conv_norm"] == "batch_renorm"):
+            raise ops.DynError(f"lockstep group of {R}: the batch ({x.shape[0]}) must hold whole chunks of R samples, with the fused subsampling / "
+                               "conv-module kernels, separate SiLU kernels and an rms_norm / layer_norm conv module")
         save = torch.is_grad_enabled()
         ctx = {} if save else None
         B, Fq, T = x.shape
@@ -389,22 +464,36 @@ class SCConformerXL:
         for b in range(B):
             ops.transpose_ft(x[b], out=xt[b])
         # --- dw_striding x8 subsampling
-        if self.fused_subsampling:
+        grp = self.R > 1
+        if self.fused_subsampling and grp:        # no group form: one launch per sample, replica k % R's filters
+            z1 = None
+            u2 = torch.empty(B, ops.out_len(ops.out_len(T)), ops.out_len(ops.out_len(Fq)), C, device=x.device, dtype=torch.float32)
+            PR = self.PR
+            for k in range(B):
+                r = k % R
+                ops.sub12_fwd(xt[k:k + 1], PR["subsampling.conv1.weight"][r], PR["subsampling.conv1.bias"][r], PR["subsampling.dw2.weight"][r],
+                              PR["subsampling.dw2.bias"][r], out=u2[k:k + 1])
+        elif self.fused_subsampling:
             z1 = None
             u2 = ops.sub12_fwd(xt, P["subsampling.conv1.weight"], P["subsampling.conv1.bias"], P["subsampling.dw2.weight"], P["subsampling.dw2.bias"])
         else:
             z1 = ops.conv2d_first(xt, P["subsampling.conv1.weight"], P["subsampling.conv1.bias"])
             u2 = ops.dwconv2d_s2(z1, P["subsampling.dw2.weight"], P["subsampling.dw2.bias"])
-        z2 = ops.linear(u2, P["subsampling.pw2.weight"], P["subsampling.pw2.bias"])
-        u3 = ops.dwconv2d_s2(z2, P["subsampling.dw3.weight"], P["subsampling.dw3.bias"])
+        z2 = ops.linear(u2, W("subsampling.pw2.weight"), W("subsampling.pw2.bias"))
+        if grp:
+            u3 = torch.empty(B, ops.out_len(z2.shape[1]), ops.out_len(z2.shape[2]), C, device=x.device, dtype=torch.float32)
+            for k in range(B):
+                ops.dwconv2d_s2(z2[k:k + 1], self.PR["subsampling.dw3.weight"][k % R], self.PR["subsampling.dw3.bias"][k % R], out=u3[k:k + 1])
+        else:
+            u3 = ops.dwconv2d_s2(z2, P["subsampling.dw3.weight"], P["subsampling.dw3.bias"])
         if self.fused_silu:
             z3 = torch.empty(*u3.shape[:-1], C, device=x.device, dtype=torch.float32) if save else None
             a3 = ops.linear(u3, P["subsampling.pw3.weight"], P["subsampling.pw3.bias"], epilogue=ops.EPI_SILU, aux=z3)
         else:
-            z3 = ops.linear(u3, P["subsampling.pw3.weight"], P["subsampling.pw3.bias"])
+            z3 = ops.linear(u3, W("subsampling.pw3.weight"), W("subsampling.pw3.bias"))
             a3 = ops.silu(z3)
         T3, F3 = a3.shape[1], a3.shape[2]
-        h = ops.linear(a3.view(B, T3, F3 * C), P["subsampling.out.weight"], P["subsampling.out.bias"])
+        h = ops.linear(a3.view(B, T3, F3 * C), W("subsampling.out.weight"), W("subsampling.out.bias"))
         if save:
             ctx["sub"] = (xt, z1, u2, z2, u3, z3, a3)
             ctx["layers"] = []
@@ -417,25 +506,25 @@ class SCConformerXL:
             h = self._attn_fwd(h, p + "attn", lc)
             h = self._conv_fwd(h, p + "conv", lc)
             h = self._ff_fwd(h, p + "ff2", lc, "ff2")
-            hn, mean, rstd = ops.layernorm(h, P[p + "norm_out.weight"], P[p + "norm_out.bias"], cfg["norm_eps"])
+            hn, mean, rstd = ops.layernorm(h, W(p + "norm_out.weight"), W(p + "norm_out.bias"), cfg["norm_eps"])
             if save:
                 lc["norm_out"] = (h, mean, rstd)
                 ctx["layers"].append(lc)
             h = hn
             if cfg["self_conditioning"] and l != nl - 1:
-                n, mean, rstd = ops.layernorm(h, P["decoder.norm.weight"], P["decoder.norm.bias"], cfg["norm_eps"])
-                z = ops.linear(n, P["decoder.ff.weight"], P["decoder.ff.bias"])
+                n, mean, rstd = ops.layernorm(h, W("decoder.norm.weight"), W("decoder.norm.bias"), cfg["norm_eps"])
+                z = ops.linear(n, W("decoder.ff.weight"), W("decoder.ff.bias"))
                 ops.softmax(z, out=z)
                 if save:
-                    h2 = ops.linear(z, P["decoder.reproj.weight"], P["decoder.reproj.bias"], beta=1.0, residual=h)
+                    h2 = ops.linear(z, W("decoder.reproj.weight"), W("decoder.reproj.bias"), beta=1.0, residual=h)
                 else:
-                    h2 = ops.linear(z, P["decoder.reproj.weight"], P["decoder.reproj.bias"], out=h, beta=1.0)
+                    h2 = ops.linear(z, W("decoder.reproj.weight"), W("decoder.reproj.bias"), out=h, beta=1.0)
                 if save:
                     ctx["sc"].append((h, mean, rstd, n, z))
                 h = h2
         self._hidden = h      # encoder states before the CTC head (the enc-dec model's cross-attention reads them)
-        n, mean, rstd = ops.layernorm(h, P["decoder.norm.weight"], P["decoder.norm.bias"], cfg["norm_eps"])
-        z = ops.linear(n, P["decoder.ff.weight"], P["decoder.ff.bias"])
+        n, mean, rstd = ops.layernorm(h, W("decoder.norm.weight"), W("decoder.norm.bias"), cfg["norm_eps"])
+        z = ops.linear(n, W("decoder.ff.weight"), W("decoder.ff.bias"))
         logp = ops.log_softmax(z, out=z)
         if save:
             ctx["head"] = (h, mean, rstd, n, logp)
@@ -444,41 +533,41 @@ class SCConformerXL:
         return {"final_posteriors": logp}
 
     def _ff_fwd(self, h, p, lc, key):
-        P, eps = self.P, self.config["norm_eps"]
-        n, mean, rstd = ops.layernorm(h, P[p + ".norm.weight"], P[p + ".norm.bias"], eps)
+        P, W, eps = self.P, self._w, self.config["norm_eps"]
+        n, mean, rstd = ops.layernorm(h, W(p + ".norm.weight"), W(p + ".norm.bias"), eps)
         if self.fused_silu:
             u = torch.empty(*n.shape[:-1], P[p + ".w1.weight"].shape[0], device=n.device, dtype=torch.float32) if lc is not None else None
             a = ops.linear(n, P[p + ".w1.weight"], epilogue=ops.EPI_SILU, aux=u)
         else:
-            u = ops.linear(n, P[p + ".w1.weight"])
+            u = ops.linear(n, W(p + ".w1.weight"))
             a = ops.silu(u)
         if lc is not None:   # keep h for the backward: the GEMM reads the residual from h and writes a new buffer
-            out = ops.linear(a, P[p + ".w2.weight"], alpha=0.5, beta=1.0, residual=h)
+            out = ops.linear(a, W(p + ".w2.weight"), alpha=0.5, beta=1.0, residual=h)
         else:
-            out = ops.linear(a, P[p + ".w2.weight"], out=h, alpha=0.5, beta=1.0)
+            out = ops.linear(a, W(p + ".w2.weight"), out=h, alpha=0.5, beta=1.0)
         if lc is not None:
             lc[key] = (h, mean, rstd, n, u, a)
         return out
 
     def _attn_fwd(self, h, p, lc):
-        cfg, P = self.config, self.P
+        cfg, W = self.config, self._w
         H, D = cfg["n_heads"], cfg["head_dim"]
         HD = H * D
         B, T, _ = h.shape
-        n, mean, rstd = ops.layernorm(h, P[p + ".norm.weight"], P[p + ".norm.bias"], cfg["norm_eps"])
-        qkv = ops.linear(n, P[p + ".qkv.weight"], P[p + ".qkv.bias"])
+        n, mean, rstd = ops.layernorm(h, W(p + ".norm.weight"), W(p + ".norm.bias"), cfg["norm_eps"])
+        qkv = ops.linear(n, W(p + ".qkv.weight"), W(p + ".qkv.bias"))
         cos, sin = self._rotary(T)
         ops.rotary(qkv, cos, sin, B, T, 2 * H, D, 3 * HD)
         if lc is not None and D == 128 and self._fused_grad_attention(T):
             O, lse = ops.attention_fwd(qkv, B, T, H, D, 1.0 / math.sqrt(D), want_lse=True)
-            out = ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], beta=1.0, residual=h)
+            out = ops.linear(O, W(p + ".out.weight"), W(p + ".out.bias"), beta=1.0, residual=h)
             lc["attn"] = (h, mean, rstd, n, qkv, lse, O)
             return out
         if lc is None and self.fused_attention and D == 128 and (B * H * ((T + 127) // 128) >= 320 or T >= 512):
             # no-grad pass: fused kernel, scores stay on chip.  Launches with too few (batch, head, query-block) workgroups to fill the
             # chip split the keys over several workgroups (dyn_attention_fwd_split: B = 1 at T' = 2048 130 us against 299 us unsplit)
             O = ops.attention_fwd(qkv, B, T, H, D, 1.0 / math.sqrt(D))
-            return ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], out=h, beta=1.0)
+            return ops.linear(O, W(p + ".out.weight"), W(p + ".out.bias"), out=h, beta=1.0)
         # samples the backward will read the probabilities of: all, or (dynamic eval) only the leading augmented copies
         Bs = B
         if lc is not None and self.grad_samples is not None and self.fused_attention and D == 128 and T >= 512:
@@ -494,9 +583,9 @@ class SCConformerXL:
         if Bs < B:      # the clean copies: scores stay on chip (key-split fused kernel), nothing kept for a backward
             ops.attention_fwd(qkv[Bs:], B - Bs, T, H, D, 1.0 / math.sqrt(D), out=O[Bs:])
         if lc is not None:
-            out = ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], beta=1.0, residual=h)
+            out = ops.linear(O, W(p + ".out.weight"), W(p + ".out.bias"), beta=1.0, residual=h)
         else:
-            out = ops.linear(O, P[p + ".out.weight"], P[p + ".out.bias"], out=h, beta=1.0)
+            out = ops.linear(O, W(p + ".out.weight"), W(p + ".out.bias"), out=h, beta=1.0)
         if lc is not None:
             lc["attn"] = (h, mean, rstd, n, qkv, S, O)
         return out
@@ -520,23 +609,25 @@ class SCConformerXL:
         return y, (None, None)
 
     def _conv_fwd(self, h, p, lc):
-        cfg, P = self.config, self.P
-        n, mean, rstd = ops.layernorm(h, P[p + ".norm.weight"], P[p + ".norm.bias"], cfg["norm_eps"])
-        u = ops.linear(n, P[p + ".pw1.weight"], P[p + ".pw1.bias"])
+        cfg, P, W = self.config, self.P, self._w
+        n, mean, rstd = ops.layernorm(h, W(p + ".norm.weight"), W(p + ".norm.bias"), cfg["norm_eps"])
+        u = ops.linear(n, W(p + ".pw1.weight"), W(p + ".pw1.bias"))
         if cfg["conv_kernel_size"] == 9 and cfg["d_model"] <= 1024 and self.fused_convmod and cfg["conv_norm"] != "batch_renorm":
             ln = cfg["conv_norm"] == "layer_norm"
-            s, g, c, nn_, cmean, crstd = ops.convmod_fwd(u, P[p + ".dw.weight"], P[p + ".dw.bias"], P[p + ".cnorm.weight"],
-                                                         P[p + ".cnorm.bias"] if ln else None, ln, cfg["norm_eps"], lc is not None)
+            s, g, c, nn_, cmean, crstd = ops.convmod_fwd(u, W(p + ".dw.weight"), W(p + ".dw.bias"), W(p + ".cnorm.weight"),
+                                                         W(p + ".cnorm.bias") if ln else None, ln, cfg["norm_eps"], lc is not None)
             stats = (cmean, crstd)
+        elif self.R > 1:
+            raise ops.DynError("lockstep group: the conv module needs the fused kernel (kernel size 9, d_model <= 1024)")
         else:
             g = ops.glu(u)
             c = ops.dwconv1d(g, P[p + ".dw.weight"], P[p + ".dw.bias"])
             nn_, stats = self._cnorm_fwd(c, p)
             s = ops.silu(nn_)
         if lc is not None:
-            out = ops.linear(s, P[p + ".pw2.weight"], P[p + ".pw2.bias"], beta=1.0, residual=h)
+            out = ops.linear(s, W(p + ".pw2.weight"), W(p + ".pw2.bias"), beta=1.0, residual=h)
         else:
-            out = ops.linear(s, P[p + ".pw2.weight"], P[p + ".pw2.bias"], out=h, beta=1.0)
+            out = ops.linear(s, W(p + ".pw2.weight"), W(p + ".pw2.bias"), out=h, beta=1.0)
         if lc is not None:
             lc["conv"] = (h, mean, rstd, n, u, g, c, stats, nn_, s)
         return out
@@ -589,7 +680,7 @@ class SCConformerXL:
             dx = self._backward_body(grad_posteriors, n_active, input_grad)
         for name, _ in self.spec:                   # after the deferred reductions have been queued: they write gradients too
             if not self.trainable(name):
-                self.G[name].zero_()
+                self.GR[name].zero_()
         return dx
 
     def _backward_body(self, grad_posteriors, n_active, input_grad):
@@ -623,7 +714,7 @@ class SCConformerXL:
         dz = ops.log_softmax_bwd(logp, grad_posteriors.contiguous())
         dn = self._lin_bwd(dz, n, "decoder.ff.weight", "decoder.ff.bias")
         dh = torch.empty_like(h)
-        ops.layernorm_bwd(h, P["decoder.norm.weight"], mean, rstd, dn, dh, G["decoder.norm.weight"], G["decoder.norm.bias"],
+        ops.layernorm_bwd(h, self._w("decoder.norm.weight"), mean, rstd, dn, dh, self._gw("decoder.norm.weight"), self._gw("decoder.norm.bias"),
                           dx_beta=0.0)
         if getattr(self, "_grad_hidden", None) is not None:
             self._check_not_queued(dh, "the encoder-state gradient")
@@ -640,8 +731,8 @@ class SCConformerXL:
             p = f"layers.{l}."
             h0, mean, rstd = lc["norm_out"]
             dh2 = torch.empty_like(dh)
-            ops.layernorm_bwd(h0, P[p + "norm_out.weight"], mean, rstd, dh, dh2, G[p + "norm_out.weight"],
-                              G[p + "norm_out.bias"], dx_beta=0.0)
+            ops.layernorm_bwd(h0, self._w(p + "norm_out.weight"), mean, rstd, dh, dh2, self._gw(p + "norm_out.weight"),
+                              self._gw(p + "norm_out.bias"), dx_beta=0.0)
             dh = dh2
             dh = self._ff_bwd(dh, p + "ff2", lc["ff2"])
             dh = self._conv_bwd(dh, p + "conv", lc["conv"])
@@ -651,11 +742,12 @@ class SCConformerXL:
         dx = self._sub_bwd(dh, ctx, input_grad)
         if self._wq:
             ops.gemm_grouped(self._wq)      # every block weight gradient (+ bias sums) of this backward: one launch
-            for wname, sh in self._shared.items():      # the per-use slabs of the shared weights, summed in use order
+            for key, sh in self._shared.items():      # the per-use slabs of the shared weights, summed in use order
                 k = sh["k"]
-                ops.reduce_partials(sh["w"][:k], self.G[wname], beta=1.0)
+                gw = self.G[key] if self.R == 1 else self.GR[sh["wname"]][sh["r"]]
+                ops.reduce_partials(sh["w"][:k], gw, beta=1.0)
                 if sh["b"] is not None:
-                    ops.reduce_partials(sh["b"][:k], self.G[sh["bname"]], beta=1.0)
+                    ops.reduce_partials(sh["b"][:k], self.G[sh["bname"]] if self.R == 1 else self.GR[sh["bname"]][sh["r"]], beta=1.0)
         self._wq = None
         self._shared = {}
         if not static:
@@ -711,13 +803,22 @@ class SCConformerXL:
         dnn = self._lin_bwd(dh, s, p + ".pw2.weight", p + ".pw2.bias", silu_of=nn_)
         dc = torch.empty_like(c)
         if cfg["conv_norm"] == "rms_norm":
-            ops.rmsnorm_bwd(c, P[p + ".cnorm.weight"], stats[1], dnn, dc, G[p + ".cnorm.weight"], dx_beta=0.0)
+            ops.rmsnorm_bwd(c, self._w(p + ".cnorm.weight"), stats[1], dnn, dc, self._gw(p + ".cnorm.weight"), dx_beta=0.0)
         elif cfg["conv_norm"] == "batch_renorm":
             ops.chanaffine_bwd(c, self.buffers[p + ".cnorm.running_mean"], self.buffers[p + ".cnorm.running_var"],
                                P[p + ".cnorm.weight"], dnn, dc, G[p + ".cnorm.weight"], G[p + ".cnorm.bias"], cfg["norm_eps"])
         else:
-            ops.layernorm_bwd(c, P[p + ".cnorm.weight"], stats[0], stats[1], dnn, dc, G[p + ".cnorm.weight"],
-                              G[p + ".cnorm.bias"], dx_beta=0.0)
+            ops.layernorm_bwd(c, self._w(p + ".cnorm.weight"), stats[0], stats[1], dnn, dc, self._gw(p + ".cnorm.weight"),
+                              self._gw(p + ".cnorm.bias"), dx_beta=0.0)
+        if self.R > 1:          # depthwise kernels have no group form: one launch per sample (= per replica in the backward)
+            dg = torch.empty_like(dc)
+            for r in range(dc.shape[0]):
+                if self.trainable(p + ".dw.weight") and not self._skip_wgrad:
+                    ops.dwconv1d_wgrad(g[r:r + 1], dc[r:r + 1], self.GR[p + ".dw.weight"][r % self.active], self.GR[p + ".dw.bias"][r % self.active], beta=1.0)
+                ops.dwconv1d_dgrad(dc[r:r + 1], self.PR[p + ".dw.weight"][r % self.active], out=dg[r:r + 1])
+            du = ops.glu_bwd(u, dg)
+            dn = self._lin_bwd(du, n, p + ".pw1.weight", p + ".pw1.bias")
+            return self._res_norm_bwd(h, p + ".norm.weight", p + ".norm.bias", mean, rstd, dn, dh)
         if self.trainable(p + ".dw.weight") and not self._skip_wgrad:
             ops.dwconv1d_wgrad(g, dc, G[p + ".dw.weight"], G[p + ".dw.bias"], beta=1.0)
         dg = ops.dwconv1d_dgrad(dc, P[p + ".dw.weight"])
@@ -736,6 +837,24 @@ class SCConformerXL:
         dz3 = self._lin_bwd(dh, a3.view(B, T3, F3 * C), "subsampling.out.weight", "subsampling.out.bias",
                             silu_of=z3.view(B, T3, F3 * C)).view_as(z3)
         du3 = self._lin_bwd(dz3, u3, "subsampling.pw3.weight", "subsampling.pw3.bias")
+        if self.R > 1:
+            if z1 is not None or input_grad:
+                raise ops.DynError("lockstep group: the subsampling backward needs the fused first two stages and no input gradient")
+            PR, GR = self.PR, self.GR
+            dz2 = torch.empty_like(z2)
+            for r in range(B):
+                q = r % self.active
+                if wg:
+                    ops.dwconv2d_s2_wgrad(z2[r:r + 1], du3[r:r + 1], GR["subsampling.dw3.weight"][q], GR["subsampling.dw3.bias"][q], beta=1.0)
+                ops.dwconv2d_s2_dgrad(z2[r:r + 1], PR["subsampling.dw3.weight"][q], du3[r:r + 1], out=dz2[r:r + 1])
+            du2 = self._lin_bwd(dz2, u2, "subsampling.pw2.weight", "subsampling.pw2.bias")
+            if wg:
+                for r in range(B):
+                    q = r % self.active
+                    ops.sub12_bwd(xt[r:r + 1], du2[r:r + 1], PR["subsampling.conv1.weight"][q], PR["subsampling.conv1.bias"][q],
+                                  PR["subsampling.dw2.weight"][q], GR["subsampling.conv1.weight"][q], GR["subsampling.conv1.bias"][q],
+                                  GR["subsampling.dw2.weight"][q], GR["subsampling.dw2.bias"][q], beta=1.0)
+            return None
         if wg:
             ops.dwconv2d_s2_wgrad(z2, du3, G["subsampling.dw3.weight"], G["subsampling.dw3.bias"], beta=1.0)
         dz2 = ops.dwconv2d_s2_dgrad(z2, P["subsampling.dw3.weight"], du3)

@@ -53,6 +53,30 @@ def _opt(t, name, dtype=F32):
     return 0 if t is None else _cc(t, name, dtype).data_ptr()
 
 
+class GroupParam:
+    """A parameter (or its gradient) of a LOCKSTEP GROUP: R recordings advance through the same window step in one batch, each with its own
+    adapted weights (model.SCConformerXL(group=R)).  `t` is the [R, *shape] view into the group's flat buffer, replicas `stride` elements
+    apart.  Batches are ordered sample = chunk * R + replica, so sample s belongs to replica s % R."""
+    __slots__ = ("t", "R", "stride")
+
+    def __init__(self, t, R, stride):
+        self.t, self.R, self.stride = t, int(R), int(stride)
+
+    @property
+    def shape(self):
+        return self.t.shape[1:]
+
+    def __getitem__(self, r):
+        return self.t[r]
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+
+def _is_group(p):
+    return isinstance(p, GroupParam)
+
+
 _WS_OWNER = None   # scratch buffer of the model whose forward/backward is being launched or captured (use_workspace)
 
 
@@ -110,7 +134,7 @@ def counters(ws):
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
          nb1=1, nb2=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, split_k=0, force=None, c_in=None,
-         epilogue=0, aux=None, ticket=None):
+         epilogue=0, aux=None, ticket=None, sbias=(0, 0)):
     """Raw strided batched GEMM (see dyn_gemm_desc). Offsets are in elements from each tensor's data_ptr.
     `force=(tile_m, tile_n, tail_slices)` pins the kernel configuration (autotuner / tests).
     `epilogue`: 0 none, EPI_SILU (C = silu(v), aux = v if given), EPI_SILU_GRAD (C = v * silu'(aux)); aux addressed like C."""
@@ -125,6 +149,7 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, M, N, K, lda, ldb, ldc, alpha
     d.B, d.ldb, d.sb1, d.sb2 = b.data_ptr() + 4 * b_off, ldb, sb[0], sb[1]
     d.C, d.ldc, d.sc1, d.sc2 = c.data_ptr() + 4 * c_off, ldc, sc[0], sc[1]
     d.bias = bias.data_ptr() if bias is not None else None
+    d.bias_s1, d.bias_s2 = sbias
     d.C_in = (c_in.data_ptr() + 4 * c_off) if c_in is not None else None   # residual source (same addressing as C)
     d.nb1, d.nb2 = nb1, nb2
     d.split_k = split_k
@@ -307,6 +332,8 @@ def gemm_profile_stop():
 def linear(x, w, bias=None, out=None, alpha=1.0, beta=0.0, residual=None, epilogue=0, aux=None):
     """out[M, N] = alpha * x[M, K] @ w[N, K]^T + beta * (residual if given else out) + bias   (torch.nn.Linear layout);
     with epilogue=EPI_SILU: out = silu(that) and aux (if given) = that."""
+    if _is_group(w):
+        return _linear_group(x, w, bias, out, alpha, beta, residual, epilogue, aux)
     _cc(x, "linear.x"); _cc(w, "linear.w")
     K = x.shape[-1]
     M = x.numel() // K
@@ -319,8 +346,42 @@ def linear(x, w, bias=None, out=None, alpha=1.0, beta=0.0, residual=None, epilog
                 epilogue=epilogue, aux=aux)
 
 
+def _group_dims(x, R, what):
+    """x [S, ..., K] with S = chunks * R samples (sample = chunk * R + replica) -> (chunks, rows per sample)."""
+    S = x.shape[0]
+    if S % R:
+        raise DynError(f"{what}: batch {S} is not a multiple of the group size {R}")
+    return S // R, x.numel() // (S * x.shape[-1])
+
+
+def _linear_group(x, w, bias, out, alpha, beta, residual, epilogue, aux):
+    """linear() over a lockstep group: ONE batched product, batch = (chunk, replica); replica r multiplies its own rows with its own weight
+    (B operand and bias step through the group's flat parameter buffer with the replica stride)."""
+    _cc(x, "linear.x")
+    R = w.R
+    N, K = w.shape
+    assert x.shape[-1] == K, (x.shape, K)
+    nch, M = _group_dims(x, R, "linear")
+    if out is None:
+        assert beta == 0.0 or residual is not None
+        out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=F32)
+    return gemm(x, w.t, out, trans_b=True, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=None if bias is None else bias.t, alpha=alpha, beta=beta,
+                c_in=residual, epilogue=epilogue, aux=aux, nb1=nch, nb2=R, sa=(R * M * K, M * K), sb=(0, w.stride), sc=(R * M * N, M * N),
+                sbias=(0, 0 if bias is None else bias.stride))
+
+
 def linear_dgrad(dy, w, out=None, alpha=1.0, beta=0.0, epilogue=0, aux=None):
     """dx[M, K] = alpha * dy[M, N] @ w[N, K] + beta * dx; with epilogue=EPI_SILU_GRAD: dx *= silu'(aux) (aux = the pre-activation)."""
+    if _is_group(w):
+        _cc(dy, "linear_dgrad.dy")
+        R = w.R
+        N, K = w.shape
+        nch, M = _group_dims(dy, R, "linear_dgrad")
+        if out is None:
+            assert beta == 0.0
+            out = torch.empty(*dy.shape[:-1], K, device=dy.device, dtype=F32)
+        return gemm(dy, w.t, out, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, alpha=alpha, beta=beta, epilogue=epilogue, aux=aux, nb1=nch, nb2=R,
+                    sa=(R * M * N, M * N), sb=(0, w.stride), sc=(R * M * K, M * K))
     _cc(dy, "linear_dgrad.dy"); _cc(w, "linear_dgrad.w")
     N, K = w.shape
     M = dy.numel() // N
@@ -499,12 +560,18 @@ def attention_bwd(qkv, out, dout, lse, B, T, H, D, scale, dqkv=None):
 
 # ----------------------------------------------------------------------------------------------- norms
 def layernorm(x, gamma, beta, eps=1e-5, out=None):
-    _cc(x, "layernorm.x"); _cc(gamma, "layernorm.gamma")
+    _cc(x, "layernorm.x")
     C = x.shape[-1]
     rows = x.numel() // C
     out = torch.empty_like(x) if out is None else _cc(out, "layernorm.out")
     mean = torch.empty(rows, device=x.device, dtype=F32)
     rstd = torch.empty(rows, device=x.device, dtype=F32)
+    if _is_group(gamma):       # lockstep group: sample s of x [S, T, C] is normalised with replica s % R's weights, one launch
+        _, rps = _group_dims(x, gamma.R, "layernorm")
+        check(_L().dyn_layernorm_fwd_g(x.data_ptr(), gamma.data_ptr(), 0 if beta is None else beta.data_ptr(), out.data_ptr(), mean.data_ptr(),
+                                       rstd.data_ptr(), rows, C, eps, rps, gamma.R, gamma.stride, _stream()), "dyn_layernorm_fwd_g")
+        return out, mean, rstd
+    _cc(gamma, "layernorm.gamma")
     check(_L().dyn_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), _opt(beta, "layernorm.beta"), out.data_ptr(),
                                  mean.data_ptr(), rstd.data_ptr(), rows, C, eps, _stream()), "dyn_layernorm_fwd")
     return out, mean, rstd
@@ -516,6 +583,13 @@ def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, dx_beta=0.0, wgra
     C = x.shape[-1]
     rows = x.numel() // C
     ws = workspace(x.device)
+    if _is_group(gamma):
+        _, rps = _group_dims(x, gamma.R, "layernorm_bwd")
+        src = dx if dx_in is None else _cc(dx_in, "layernorm_bwd.dx_in")
+        check(_L().dyn_layernorm_bwd_g(x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), src.data_ptr(),
+                                       dx.data_ptr(), dx_beta, 0 if dgamma is None else dgamma.data_ptr(), 0 if dbeta is None else dbeta.data_ptr(),
+                                       wgrad_beta, rows, C, rps, gamma.R, gamma.stride, ws.data_ptr(), ws.numel(), _stream()), "dyn_layernorm_bwd_g")
+        return dx
     if dx_in is not None:
         _cc(dx_in, "layernorm_bwd.dx_in")
         check(_L().dyn_layernorm_bwd_res(x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx_in.data_ptr(),
@@ -564,6 +638,12 @@ def rmsnorm_bwd(x, gamma, rstd, dy, dx, dgamma, dx_beta=0.0, wgrad_beta=1.0):
     C = x.shape[-1]
     rows = x.numel() // C
     ws = workspace(x.device)
+    if _is_group(gamma):
+        _, rps = _group_dims(x, gamma.R, "rmsnorm_bwd")
+        check(_L().dyn_rmsnorm_bwd_g(x.data_ptr(), gamma.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(), dx_beta,
+                                     0 if dgamma is None else dgamma.data_ptr(), wgrad_beta, rows, C, rps, gamma.R, gamma.stride,
+                                     ws.data_ptr(), ws.numel(), _stream()), "dyn_rmsnorm_bwd_g")
+        return dx
     check(_L().dyn_rmsnorm_bwd(x.data_ptr(), gamma.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(), dx_beta,
                                _opt(dgamma, "dgamma"), wgrad_beta, rows, C, ws.data_ptr(), ws.numel(), _stream()),
           "dyn_rmsnorm_bwd")
@@ -656,8 +736,9 @@ def dwconv1d_wgrad(x, dy, dw, dbias, beta=1.0):
 
 
 def convmod_fwd(u, w, bias, gamma, beta, layernorm, eps, save):
-    """Fused GLU -> dwconv(k=9) -> norm -> SiLU.  u [B, T, 2C] -> s [B, T, C]; with `save` also (g, c, nn, mean, rstd)."""
-    _cc(u, "convmod.u"); _cc(w, "convmod.w")
+    """Fused GLU -> dwconv(k=9) -> norm -> SiLU.  u [B, T, 2C] -> s [B, T, C]; with `save` also (g, c, nn, mean, rstd).
+    Lockstep group (w a GroupParam): one launch per sample into shared output tensors (sample s: replica s % R's weights)."""
+    _cc(u, "convmod.u")
     B, T, C2 = u.shape
     C = C2 // 2
     dev = u.device
@@ -667,6 +748,19 @@ def convmod_fwd(u, w, bias, gamma, beta, layernorm, eps, save):
         g, c, nn = (torch.empty(B, T, C, device=dev, dtype=F32) for _ in range(3))
         rstd = torch.empty(B * T, device=dev, dtype=F32)
         mean = torch.empty(B * T, device=dev, dtype=F32) if layernorm else None
+    if _is_group(w):
+        R = w.R
+        _group_dims(u, R, "convmod")
+        for k in range(B):
+            r = k % R
+            sl = slice(k * T, (k + 1) * T)
+            check(_L().dyn_convmod_fwd(u[k].data_ptr(), w[r].data_ptr(), 0 if bias is None else bias[r].data_ptr(), gamma[r].data_ptr(),
+                                       0 if beta is None else beta[r].data_ptr(), s[k].data_ptr(), 0 if g is None else g[k].data_ptr(),
+                                       0 if c is None else c[k].data_ptr(), 0 if nn is None else nn[k].data_ptr(),
+                                       0 if mean is None else mean[sl].data_ptr(), 0 if rstd is None else rstd[sl].data_ptr(), 1, T, C, w.shape[1],
+                                       int(layernorm), eps, _stream()), "dyn_convmod_fwd")
+        return s, g, c, nn, mean, rstd
+    _cc(w, "convmod.w")
     check(_L().dyn_convmod_fwd(u.data_ptr(), w.data_ptr(), _opt(bias, "bias"), gamma.data_ptr(), _opt(beta, "beta"), s.data_ptr(),
                                _opt(g, "g"), _opt(c, "c"), _opt(nn, "nn"), _opt(mean, "mean"), _opt(rstd, "rstd"), B, T, C, w.shape[1],
                                int(layernorm), eps, _stream()), "dyn_convmod_fwd")

@@ -76,6 +76,9 @@ typedef struct {
      * used when counters == NULL or there are fewer counters than partial tiles). */
     int32_t* counters;
     int64_t n_counters;
+    /* batch strides of `bias` in elements (0, 0 = the same [N] row for every batch): a product batched over SEVERAL WEIGHT MATRICES —
+     * the lockstep group of recordings, each with its own adapted weights (sb1 / sb2 step through the weights) — adds each weight's own bias. */
+    int64_t bias_s1, bias_s2;
 } dyn_gemm_desc;
 
 int64_t dyn_gemm_f32_workspace_bytes(const dyn_gemm_desc* d);
@@ -137,6 +140,21 @@ int dyn_rmsnorm_fwd(const float* x, const float* gamma, float* y, float* rstd, i
 int dyn_rmsnorm_bwd(const float* x, const float* gamma, const float* rstd, const float* dy, float* dx, float dx_beta,
                     float* dgamma, float wgrad_beta, int64_t rows, int64_t C, void* workspace, int64_t workspace_bytes,
                     void* stream);
+/* Lockstep-group variants (r04).  Several recordings advance through the same window step in ONE batch, each with its own adapted weights
+ * (recordings are independent: fresh optimiser and restored weights per eval_fn call, reference lcasr/lib.py:494,636-637).  `rows` =
+ * n_samples * rows_per_sample; sample s takes the parameters of group s % n_groups, the groups' parameters lie param_stride elements apart
+ * (the group's flat parameter buffer is [n_groups, n_flat]); weight gradients of group g go to dgamma + g * param_stride (a group's second
+ * sample accumulates onto its first).  n_groups = 1 is exactly the plain entry; per sample the arithmetic, the partial-sum layout and the
+ * reduction order are those of a plain launch over that sample's rows: bit-identical to running the recordings one by one. */
+int64_t dyn_norm_bwd_workspace_bytes_g(int64_t rows, int64_t C, int64_t rows_per_sample);
+int dyn_layernorm_fwd_g(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows, int64_t C,
+                        float eps, int64_t rows_per_sample, int64_t n_groups, int64_t param_stride, void* stream);
+int dyn_layernorm_bwd_g(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, const float* dx_in,
+                        float* dx, float dx_beta, float* dgamma, float* dbeta, float wgrad_beta, int64_t rows, int64_t C,
+                        int64_t rows_per_sample, int64_t n_groups, int64_t param_stride, void* workspace, int64_t workspace_bytes, void* stream);
+int dyn_rmsnorm_bwd_g(const float* x, const float* gamma, const float* rstd, const float* dy, float* dx, float dx_beta, float* dgamma,
+                      float wgrad_beta, int64_t rows, int64_t C, int64_t rows_per_sample, int64_t n_groups, int64_t param_stride,
+                      void* workspace, int64_t workspace_bytes, void* stream);
 /* BatchRenorm1d in eval mode = per-channel affine with the running statistics (the loop calls model.eval(), reference
  * lcasr/lib.py:525, so they are constants):  y = (x - mean_c) * rsqrt(var_c + eps) * weight_c + bias_c;  x, y [rows, C].
  * bwd: dx = dy * rsqrt(var + eps) * weight (+ dx_beta * dx), dweight += sum_r dy * xhat, dbias += sum_r dy (deterministic). */

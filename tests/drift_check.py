@@ -99,6 +99,34 @@ def with_progress(fn, timings, total, label):
     return box["out"]
 
 
+class LabelLog:
+    """Tokenizer wrapper that records what every tokenizer.encode() call returned: the pseudo-label ids each adapt step trained on.
+    A near-tie that flips ONE frame's argmax between two fp32 implementations changes a window's target sequence, and from that step on
+    the two runs follow different gradients — a divergence of another kind (1e-2) than rounding drift (1e-3)."""
+    def __init__(self, tok):
+        self.tok, self.log = tok, []
+
+    def vocab_size(self):
+        return self.tok.vocab_size()
+
+    def decode(self, ids):
+        return self.tok.decode(ids)
+
+    def encode(self, text):
+        ids = self.tok.encode(text)
+        self.log.append(list(ids))
+        return ids
+
+
+def label_agreement(a, b):
+    """Per adapt step: do both runs train on the same pseudo-label ids?  -> summary dict."""
+    n = min(len(a), len(b))
+    diff = [k for k in range(n) if a[k] != b[k]]
+    return {"steps": n, "steps_with_different_labels": len(diff), "first_different_step": diff[0] if diff else None,
+            "label_lengths": [len(x) for x in a[:n]][:200],
+            "edit_distance_at_differing_steps": [edit_distance(a[k], b[k]) for k in diff[:50]]}
+
+
 def make_args(masks, online, lr):
     ns = argparse.Namespace()
     ns.config = {'model': {'subsampling_factor': 8}, 'audio_chunking': {'size': SEQ, 'overlap': 0}, 'training': {'max_seq_len': 0}}
@@ -135,6 +163,13 @@ def main():
     hip = SCConformerXL(vocab_size=VOCAB, device=dev)
     hip.load_state_dict(ref.state_dict())
     tok = SyntheticTokenizer(VOCAB)
+
+    def logged(log_tok):
+        """With --label_tokens the loop trains on substituted ids; the log then records the model's OWN labels (the text hop it still makes)."""
+        if a.label_tokens > 0:
+            from bench import SubstituteLabelTokenizer
+            return SubstituteLabelTokenizer(log_tok, a.label_tokens)
+        return log_tok
     if a.label_tokens > 0:
         from bench import SubstituteLabelTokenizer
         tok = SubstituteLabelTokenizer(tok, a.label_tokens)
@@ -162,16 +197,18 @@ def main():
     res.update({"windows": len(keys), "frames": n_frames, "keys": keys})
 
     t0 = time.time()
-    hip_off = lib.dynamic_eval(make_args(masks, False, a.lr), hip, spec, SEQ, OVL, tok, use_tqdm=False)
+    log_hip, log_f32 = LabelLog(SyntheticTokenizer(VOCAB)), LabelLog(SyntheticTokenizer(VOCAB))
+    hip_off = lib.dynamic_eval(make_args(masks, False, a.lr), hip, spec, SEQ, OVL, logged(log_hip), use_tqdm=False)
     hip_on = lib.dynamic_eval(make_args(masks, True, a.lr), hip, spec, SEQ, OVL, tok, use_tqdm=False)
     res["hip_seconds"] = round(time.time() - t0, 2)
     print(f"[drift] HIP done in {res['hip_seconds']} s", flush=True)
     t0 = time.time()
     tm32 = {}
-    f32_off, f32_on, p32 = with_progress(lambda: R.dynamic_eval_ref(ref, spec, SEQ, OVL, tok, MADGRAD_REF, {'lr': a.lr}, {}, fixed_masks=masks,
+    f32_off, f32_on, p32 = with_progress(lambda: R.dynamic_eval_ref(ref, spec, SEQ, OVL, logged(log_f32), MADGRAD_REF, {'lr': a.lr}, {}, fixed_masks=masks,
                                                                     also_online=True, return_params=True, timings=tm32), tm32, len(keys), "fp32 oracle")
     res["oracle_f32_seconds"] = round(time.time() - t0, 1)
-    print(f"[drift] fp32 oracle done in {res['oracle_f32_seconds']} s", flush=True)
+    res["pseudo_labels_hip_vs_f32"] = label_agreement(log_hip.log, log_f32.log)
+    print(f"[drift] fp32 oracle done in {res['oracle_f32_seconds']} s; pseudo-labels: {json.dumps({k: v for k, v in res['pseudo_labels_hip_vs_f32'].items() if k != 'label_lengths'})}", flush=True)
     for name, x, y in (("offline_hip_vs_f32", hip_off, f32_off), ("online_hip_vs_f32", hip_on, f32_on)):
         d, bad = bands(x, y)
         hyp, want = greedy_ids(x, VOCAB), greedy_ids(y, VOCAB)

@@ -210,7 +210,10 @@ def test_bench_contract(cuda):
     assert d["hyp_tokens_total"] >= 0 and "wer_counters" not in d
     # the path's other loops get a driver-visible number too (untimed for `value`)
     ow = d["other_workloads"]
-    assert set(ow) == {"awmc", "wav2vec2_su", "enc_dec_teacher_ce"} and all(v.get("value", 0) > 0 and v["unit"] == "audio-s/s" for v in ow.values()), ow
+    assert set(ow) == {"awmc", "wav2vec2_su", "enc_dec_teacher_ce", "soft_dtw"}, ow
+    assert all(v.get("value", 0) > 0 and v["unit"] == "audio-s/s" for k, v in ow.items() if k != "soft_dtw"), ow
+    assert len(ow["soft_dtw"]) == 4 and all(r["value_matches_oracle"] and r["us_per_diagonal"] > 0 for r in ow["soft_dtw"]), ow["soft_dtw"]
+    assert 0 < ow["wav2vec2_su"]["roofline"]["frac"] < 1
 
 
 def test_run_cross_speaker_gender(cuda, tmp_path, capsys):

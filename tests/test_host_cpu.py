@@ -320,7 +320,7 @@ def test_product_package_never_imports_the_oracle():
     tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
     for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
         uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
-        assert not uses or fn.name == "cpu_baseline", f"bench.py:{fn.name} imports the oracle"
+        assert not uses or fn.name.startswith("cpu_baseline"), f"bench.py:{fn.name} imports the oracle outside the cpu_baseline leg"
     # and the product fails loudly, not silently, when the HIP library is absent
     from dynamic_asr_eval_amd import _lib
     code = ("import os, sys; sys.path.insert(0, %r); os.environ['DYN_LIB_PATH'] = '/nonexistent/libdyneval_hip.so'\n"

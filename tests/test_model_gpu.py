@@ -564,3 +564,108 @@ def test_dynamic_eval_with_empty_pseudo_labels(cuda):
     assert moved > 1e-7
     for a, b in zip(params, params_ref):
         assert (a - b).abs().max().item() < 5e-5
+
+
+def test_lockstep_group_matches_separate_models(cuda):
+    """SCConformerXL(group=R): R replicas with DIFFERENT weights in one object, batches ordered sample = chunk * R + replica.  Forward
+    log-probs and every replica's parameter gradients against R separate single models on the same inputs (the grouped launches may pick
+    other GEMM tiles than the single ones: 2e-5 on log-probs, 1e-4 relative on gradients; row-wise kernels are the same per-sample
+    arithmetic), eager and through the hipGraph replay, and with fewer active replicas than the group holds."""
+    from dynamic_asr_eval_amd.model import SCConformerXL
+    from oracle.conformer_ref import SCConformerXLRef
+    R, T = 3, 300
+    refs = [SCConformerXLRef(SMALL, vocab_size=128, seed=40 + r, blank_bias=0.5) for r in range(R)]
+    singles = []
+    for ref in refs:
+        m = SCConformerXL(SMALL, vocab_size=128, device=cuda)
+        m.load_state_dict(ref.state_dict())
+        singles.append(m)
+    grp = SCConformerXL(SMALL, vocab_size=128, device=cuda, group=R)
+    for r, ref in enumerate(refs):
+        sd = ref.state_dict()
+        for n, _ in grp.spec:
+            grp.PR[n][r].copy_(sd[n].to(cuda).reshape(grp.PR[n][r].shape))
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2 * R, 80, T, generator=g).to(cuda)             # samples 0..R-1: "augmented" copies, R..2R-1: "clean" copies
+
+    def run_group(active, use_graphs, reps):
+        grp.active, grp.use_graphs, grp.grad_samples = active, use_graphs, active
+        xa = torch.cat([x[:active], x[R:R + active]]).contiguous()
+        for _ in range(reps):
+            with torch.enable_grad():
+                out = grp(audio_signal=xa)['final_posteriors']
+            gp = torch.zeros_like(out[:active])
+            gp.copy_(gl[:active])
+            grp.zero_grad()
+            grp.backward(gp, n_active=active)
+        return out.clone(), grp.flat_grads.view(R, grp.n_flat).clone()
+
+    outs, grads = [], []
+    Tp = None
+    for r, m in enumerate(singles):
+        m.grad_samples = 1
+        with torch.enable_grad():
+            o = m(audio_signal=torch.stack([x[r], x[R + r]]))['final_posteriors']
+        Tp = o.shape[1]
+        outs.append(o.clone())
+    gl = (torch.randn(R, Tp, 129, generator=g) / (Tp * 129)).to(cuda)
+    for r, m in enumerate(singles):
+        m.zero_grad()
+        m.backward(gl[r:r + 1].contiguous(), n_active=1)
+        grads.append(m.flat_grads.clone())
+    for active, use_graphs, reps in ((R, False, 1), (R, True, 3), (2, False, 1), (1, True, 3)):
+        og, gg = run_group(active, use_graphs, reps)
+        for r in range(active):
+            for c, k in ((0, r), (1, active + r)):
+                err = (og[k] - outs[r][c]).abs().max().item()
+                assert err < 2e-5, f"active {active} graphs {use_graphs}: replica {r} copy {c}: log-probs differ by {err}"
+            denom = grads[r].abs().max().item()
+            rel = (gg[r] - grads[r]).abs().max().item() / denom
+            assert rel < 1e-4, f"active {active} graphs {use_graphs}: replica {r}: gradients differ by {rel} (relative)"
+            # per tensor too: a gradient written to the wrong replica or slot shows up here, not in the global maximum
+            for n, (o, cnt, shape) in grp._slots.items():
+                a, b = gg[r][o:o + cnt], grads[r][o:o + cnt]
+                d = b.abs().max().item()
+                assert (a - b).abs().max().item() <= 2e-4 * d + 1e-9, (active, use_graphs, r, n)
+        for r in range(active, R):
+            assert gg[r].abs().max().item() == 0.0, "inactive replicas receive no gradient"
+    grp.active, grp.grad_samples = R, None
+
+
+def test_lockstep_dynamic_eval_matches_one_recording_at_a_time(cuda):
+    """lib.dynamic_eval_lockstep (R recordings of equal length advance through every window step together) against lib.dynamic_eval on each
+    recording alone, same weights, per-recording stored masks: stitched log-probs within 2e-4 (the weights carry the tile-choice rounding
+    through the MADGRAD steps), identical argmax ids, adapted parameters within 5e-5, the group's weights restored; offline and online."""
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.model import SCConformerXL
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    from oracle import dynamic_eval_ref as R_
+    from oracle.conformer_ref import SCConformerXLRef
+    R, vocab = 3, 128
+    ref = SCConformerXLRef(SMALL, vocab_size=vocab, seed=5, blank_bias=1.5)
+    single = SCConformerXL(SMALL, vocab_size=vocab, device=cuda)
+    single.load_state_dict(ref.state_dict())
+    grp = SCConformerXL(SMALL, vocab_size=vocab, device=cuda, group=R)
+    grp.load_state_dict(ref.state_dict())
+    tok = SyntheticTokenizer(vocab)
+    g = torch.Generator().manual_seed(21)
+    specs = [torch.randn(1, 80, 1500, generator=g) for _ in range(R)]
+    _, keys = R_.prepare_chunks(specs[0], 512, 256)
+    masks = [_masks_for(keys, 80, None, seed=30 + r) for r in range(R)]
+    for online in (False, True):
+        want = []
+        for r in range(R):
+            a = _args(optim_lr=1e-4, epochs=1, shuffle=False, online=online, spec_augment_fixed_masks=masks[r], quiet=True)
+            want.append(lib.dynamic_eval(a, single, specs[r], 512, 256, tok, use_tqdm=False, return_params=True))
+        for n_rec in (R, 2):
+            a = _args(optim_lr=1e-4, epochs=1, shuffle=False, online=online, spec_augment_fixed_masks=masks[:n_rec], quiet=True)
+            before = grp.flat_params.clone()
+            got = lib.dynamic_eval_lockstep(a, grp, specs[:n_rec], 512, 256, tok, use_tqdm=False, return_params=True)
+            assert torch.equal(grp.flat_params, before), "the group's weights must be restored"
+            assert len(got) == n_rec
+            for r in range(n_rec):
+                (o, p), (ow, pw) = got[r], want[r]
+                assert o.shape == ow.shape and np.abs(o - ow).max() < 2e-4, (online, n_rec, r, np.abs(o - ow).max())
+                assert np.array_equal(o.argmax(-1), ow.argmax(-1))
+                for x, y in zip(p, pw):
+                    assert (x - y).abs().max().item() < 5e-5
