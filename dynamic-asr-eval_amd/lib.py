@@ -448,8 +448,8 @@ def _dynamic_eval_gen(
 
 def lockstep_supported(args, model, specs, beam_search_fn=None, optimizer_state=None):
     """Can `specs` go through ONE lockstep group of `model` (SCConformerXL(group=R))?  The group form covers the standard recipe (SpecAugment
-    on copy 0, MADGRAD / Adam, online or final pass, epochs, shuffle); the optional augmentations, optimiser state hand-over, LM beam search
-    and recordings of different lengths keep the one-recording-per-chain path."""
+    on copy 0, MADGRAD / Adam, online or final pass, epochs, shuffle, recordings of different lengths); the optional augmentations,
+    optimiser state hand-over and LM beam search keep the one-recording-per-chain path."""
     a = args.__dict__
     if not (_is_native(model) and getattr(model, "R", 1) > 1 and 1 <= len(specs) <= model.R):
         return False
@@ -461,30 +461,47 @@ def lockstep_supported(args, model, specs, beam_search_fn=None, optimizer_state=
         return False
     if not a.get('skip_zero_grad_samples', True):
         return False
-    return len({int(sp.shape[-1]) for sp in specs}) == 1
+    if len({int(sp.shape[-1]) for sp in specs}) > 1 and (a.get('epochs', 1) != 1 or (a.get('shuffle', False) and not a.get('online', False))):
+        return False        # one optimiser step counter per group: recordings of different lengths stay in step only over ONE in-order epoch
+    return len({int(sp.shape[-2]) for sp in specs}) == 1
+
+
+def _shape_classes(members, u_lens):
+    """Contiguous runs [lo, hi) of `members` (ascending replica indices) whose windows have the same length."""
+    out, k = [], 0
+    while k < len(members):
+        j = k
+        while j + 1 < len(members) and members[j + 1] == members[j] + 1 and u_lens[members[j + 1]] == u_lens[members[k]]:
+            j += 1
+        out.append((members[k], members[j] + 1))
+        k = j + 1
+    return out
 
 
 def _dynamic_eval_group_gen(args, model, specs, seq_len, overlap, tokenizer, use_tqdm=True, optim=MADGRAD, optimizer_state=None,
                             beam_search_fn=None, return_params=False, return_device=False):
-    """dynamic_eval_ctc_loss (reference lcasr/lib.py:450-640) for R' = len(specs) recordings of EQUAL length in lockstep on one
-    SCConformerXL(group=R >= R'): every window step runs ONCE for all of them — batch [2 R', F, T] ordered (augmented copies of recordings
-    0 .. R'-1, then their clean copies), one forward, one greedy decode, one CTC launch over the R' augmented copies (each recording's loss
-    and gradient scaled as if it were alone: reduction 'sum', 1 / (N * B) with B = 1), one backward on the R' augmented samples, one
-    optimiser launch over the [R', n_flat] buffers.  Recordings stay independent (own weights, own optimiser state, own stitch buffers):
-    per recording the results are those of `dynamic_eval` up to the GEMM planner's choice of tile for the larger launches.
-    Generator with the same yield points as _dynamic_eval_gen; returns the list of per-recording results in StopIteration.value."""
+    """dynamic_eval_ctc_loss (reference lcasr/lib.py:450-640) for R' = len(specs) recordings in lockstep on one SCConformerXL(group=R >= R'):
+    every window step runs ONCE for all recordings that have a window of that shape at that position — batch [2 n, F, T] ordered (augmented
+    copies of the n recordings, then their clean copies), one forward, one greedy decode, one CTC launch over the n augmented copies (each
+    recording's loss and gradient scaled as if it were alone: reduction 'sum', 1 / (N * B) with B = 1), one backward on the n augmented
+    samples — and ONE optimiser launch over the [n, n_flat] buffers of the recordings still adapting.  Recordings of different lengths share
+    the window grid (same seq_len / overlap): they are ordered longest first, the full windows run on a shrinking prefix of the replicas,
+    a recording's short last window runs on its own replica, and a finished recording's replica is no longer stepped.  Recordings stay
+    independent (own weights, own optimiser state, own stitch buffers): per recording the results are those of `dynamic_eval` up to the GEMM
+    planner's choice of tile for the larger launches.  Generator with the same yield points as _dynamic_eval_gen; returns the list of
+    per-recording results (in `specs` order) in StopIteration.value."""
     if not lockstep_supported(args, model, specs, beam_search_fn, optimizer_state):
         raise ops.DynError("dynamic_eval lockstep group: unsupported configuration (see lockstep_supported)")
     device = model.device
     Rn = len(specs)
-    spec_n = specs[0].shape[-1]
+    order = sorted(range(Rn), key=lambda j: (-int(specs[j].shape[-1]), j))        # replica q holds recording order[q]: longest first
     downsampling_factor = args.config['model']['subsampling_factor']
     seq_len = seq_len if seq_len != -1 else args.config['audio_chunking']['size']
     spec_augment_config = get_specaugment_config_from_args(args)
     lr_args = get_lr_args_from_args(args)
     num_negatives = 1
-    prev_active = model.active
-    model.active = Rn
+    prev_range = (model._lo, model._lo + model._n)
+    model.set_range(0, Rn)
     n_flat = model.n_flat
     original_flat = model.flat_params[:Rn * n_flat].clone()
     num_classes = model.decoder.num_classes
@@ -492,72 +509,89 @@ def _dynamic_eval_group_gen(args, model, specs, seq_len, overlap, tokenizer, use
     optimizer = optim(model.parameters(), **lr_args)             # flat [R', n_flat] buffers: one launch per step for the whole group
     augmentation = SpecAugment(**spec_augment_config)
     fixed_masks = args.__dict__.get('spec_augment_fixed_masks', None)  # test hook: {window_key: masks} or one such dict per recording
-    if seq_len > spec_n:
-        seq_len, overlap = spec_n, 0
-    else:
-        overlap = overlap if overlap != -1 else args.config['audio_chunking']['overlap']
     assert args.config['training'].get("max_seq_len", 0) == 0, 'caching is not used anymore'
-    assert overlap / downsampling_factor == overlap // downsampling_factor, 'Overlap must be a multiple of the downsampling factor'
     assert tokenizer.vocab_size() + 1 == num_classes, 'tokenizer vocabulary does not match the CTC head'
     epochs = args.__dict__.get('epochs', 1)
     shuffle = args.__dict__.get('shuffle', False)
     online = args.__dict__.get('online', False)
     shuffle = False if online else shuffle
     final_batch = max(1, int(args.__dict__.get('final_pass_batch', 4)))
-    specs_dev = [sp.to(device=device, dtype=torch.float32) for sp in specs]
-    for sp in specs_dev:
+    specs_dev = []
+    for q in range(Rn):
+        sp = specs[order[q]].to(device=device, dtype=torch.float32)
         if sp.dim() != 3 or sp.shape[0] != 1:
             raise ops.DynError(f"spec must be [1, F, T], got {tuple(sp.shape)}")
+        specs_dev.append(sp)
     Fq = specs_dev[0].shape[1]
-    acc_rows = spec_n // 4 + seq_len
-    acc = [torch.zeros(acc_rows, num_classes, device=device, dtype=torch.float32) for _ in range(Rn)]
-    cnt = [torch.zeros(acc_rows, device=device, dtype=torch.float32) for _ in range(Rn)]
-    stitch = [{"pos": 0, "end": 0} for _ in range(Rn)]
+    # per recording: window rule and accumulators exactly as the single path (a recording shorter than seq_len is one window, overlap 0)
+    seqs, ovls, data, acc, cnt, stitch = [], [], [], [], [], []
+    for q in range(Rn):
+        spec_n = specs_dev[q].shape[-1]
+        sl, ov = (spec_n, 0) if seq_len > spec_n else (seq_len, overlap if overlap != -1 else args.config['audio_chunking']['overlap'])
+        assert ov / downsampling_factor == ov // downsampling_factor, 'Overlap must be a multiple of the downsampling factor'
+        seqs.append(sl); ovls.append(ov)
+        data.append(prepare_chunks(specs_dev[q], sl, ov)[0])
+        rows = spec_n // 4 + sl
+        acc.append(torch.zeros(rows, num_classes, device=device, dtype=torch.float32))
+        cnt.append(torch.zeros(rows, device=device, dtype=torch.float32))
+        stitch.append({"pos": 0, "end": 0})
+    if len({(sl - ov) for sl, ov, d in zip(seqs, ovls, data) if len(d) > 1}) > 1:
+        raise ops.DynError("lockstep group: recordings must share the window stride")
 
-    def stitch_window(r, key, log_probs_2d, u_len):
+    def stitch_window(q, key, log_probs_2d, u_len):
         ds_len = log_probs_2d.shape[0]
-        overlap_ds = int(overlap / (u_len / ds_len))
-        st = stitch[r]
+        overlap_ds = int(ovls[q] / (u_len / ds_len))
+        st = stitch[q]
         st["pos"] -= overlap_ds if key != 0 else 0
-        ops.stitch_accumulate(log_probs_2d, acc[r], cnt[r], st["pos"])
+        ops.stitch_accumulate(log_probs_2d, acc[q], cnt[q], st["pos"])
         st["pos"] += ds_len
         st["end"] = max(st["end"], st["pos"])
 
     model.use_graphs = bool(args.__dict__.get('use_graphs', True))
-    model.grad_samples = num_negatives * Rn if _CLEAN_COPY_FUSED_ATTN else None
     model.eval()
-    data = [prepare_chunks(sp, seq_len, overlap)[0] for sp in specs_dev]
+    all_keys = sorted(set().union(*[set(d.keys()) for d in data]))
     pinned = None
     tgt_ring, tgt_turn = None, 0
+    results = [None] * Rn
     try:
         for epoch in range(args.__dict__.get('epochs', 1)):
             if online and epoch > 0:
-                for r in range(Rn):
-                    acc[r].zero_(); cnt[r].zero_()
-                    stitch[r]["pos"] = stitch[r]["end"] = 0
-            training_keys = list(data[0].keys())
-            training_keys = random.sample(training_keys, len(training_keys)) if shuffle else training_keys
+                for q in range(Rn):
+                    acc[q].zero_(); cnt[q].zero_()
+                    stitch[q]["pos"] = stitch[q]["end"] = 0
+            training_keys = random.sample(all_keys, len(all_keys)) if shuffle else list(all_keys)
             for i in (tqdm(training_keys) if use_tqdm else training_keys):
+                members = [q for q in range(Rn) if i in data[q]]
+                u_lens = {q: data[q][i].shape[-1] for q in members}
+                classes = _shape_classes(members, u_lens)
                 sampled = 0
                 if ops.gemm_profile_active():
                     sampled = ops.gemm_profile_begin_step(device)
-                u_len = data[0][i].shape[-1]
-                audio_chunk = torch.empty(2 * Rn, Fq, u_len, device=device, dtype=torch.float32)
-                for r in range(Rn):
-                    view = data[r][i][0]
-                    audio_chunk[r].copy_(view)
-                    audio_chunk[Rn + r].copy_(view)
-                    fm = fixed_masks[r] if isinstance(fixed_masks, (list, tuple)) else fixed_masks
-                    masks = fm[i] if fm is not None else augmentation.draw(Fq, u_len)
-                    if masks[0][0] or masks[1][0]:
-                        augmentation.apply(audio_chunk[r], masks, _window_fill_value(audio_chunk[r], augmentation.zero_masking))
-                with torch.enable_grad():
-                    post = model(audio_signal=audio_chunk)['final_posteriors']     # [2 R', N, C]
-                ids_dev, n_dev = ops.ctc_greedy(post[Rn:].detach(), blank)       # pseudo-labels of the clean copies
-                if pinned is None or pinned[0].shape[1] < ids_dev.shape[1]:
-                    pinned = (torch.empty(Rn, ids_dev.shape[1], dtype=torch.int32, pin_memory=True), torch.empty(Rn, dtype=torch.int32, pin_memory=True))
-                pinned[0][:, :ids_dev.shape[1]].copy_(ids_dev, non_blocking=True)
-                pinned[1].copy_(n_dev, non_blocking=True)
+                posts = []
+                for lo, hi in classes:               # forward of every shape class; the labels of all of them cross PCIe together
+                    n = hi - lo
+                    u_len = u_lens[lo]
+                    audio_chunk = torch.empty(2 * n, Fq, u_len, device=device, dtype=torch.float32)
+                    for q in range(lo, hi):
+                        view = data[q][i][0]
+                        audio_chunk[q - lo].copy_(view)
+                        audio_chunk[n + q - lo].copy_(view)
+                        fm = fixed_masks[order[q]] if isinstance(fixed_masks, (list, tuple)) else fixed_masks
+                        masks = fm[i] if fm is not None else augmentation.draw(Fq, u_len)
+                        if masks[0][0] or masks[1][0]:
+                            augmentation.apply(audio_chunk[q - lo], masks, _window_fill_value(audio_chunk[q - lo], augmentation.zero_masking))
+                    model.set_range(lo, hi)
+                    model.grad_samples = num_negatives * n if _CLEAN_COPY_FUSED_ATTN else None
+                    with torch.enable_grad():
+                        post = model(audio_signal=audio_chunk)['final_posteriors']     # [2 n, N, C]
+                    ctx = (model._ctx, model._ctx_static, model._ctx_key)
+                    ids_dev, n_dev = ops.ctc_greedy(post[n:].detach(), blank)       # pseudo-labels of the clean copies
+                    if pinned is None or pinned[0].shape[1] < ids_dev.shape[1]:
+                        pinned = (torch.empty(Rn, max(ids_dev.shape[1], seq_len // downsampling_factor), dtype=torch.int32, pin_memory=True),
+                                  torch.empty(Rn, dtype=torch.int32, pin_memory=True))
+                    pinned[0][lo:hi, :ids_dev.shape[1]].copy_(ids_dev, non_blocking=True)
+                    pinned[1][lo:hi].copy_(n_dev, non_blocking=True)
+                    posts.append((post, ctx))
                 ready = torch.cuda.Event()
                 ready.record()
                 if sampled:
@@ -568,75 +602,99 @@ def _dynamic_eval_group_gen(args, model, specs, seq_len, overlap, tokenizer, use
                     ops.gemm_profile_resume_step(device, sampled)
                 ready.synchronize()
                 HOST_WAIT[0] += time.perf_counter() - _t0
-                target_ids = []
-                for r in range(Rn):
-                    pseudo_targets = tokenizer.decode(pinned[0][r, :int(pinned[1][r])].tolist())
-                    target_ids.append(tokenizer.encode(pseudo_targets))                   # text hop kept (reference lib.py:569)
-                S_max = max(1, max(len(t) for t in target_ids))
-                if tgt_ring is None or tgt_ring[0].shape[1] < S_max:
-                    tgt_ring = [torch.zeros(Rn, max(2 * S_max, 256), dtype=torch.int32, pin_memory=True) for _ in range(4)]
-                slot = tgt_ring[tgt_turn % 4]
-                lens = tgt_ring_len = torch.empty(Rn, dtype=torch.int32, pin_memory=True)
-                tgt_turn += 1
-                for r, t in enumerate(target_ids):
-                    if t:
-                        slot[r, :len(t)] = torch.as_tensor(t, dtype=torch.int32)
-                    lens[r] = len(t)
-                targets = torch.empty(Rn, S_max, dtype=torch.int32, device=device)
-                targets.copy_(slot[:, :S_max], non_blocking=True)
-                tlen = torch.empty(Rn, dtype=torch.int32, device=device)
-                tlen.copy_(tgt_ring_len, non_blocking=True)
-                N = post.shape[1]
-                ilen = torch.full((Rn,), N, dtype=torch.int32, device=device)
-                # per recording: CTCLoss(reduction='sum') / (N * B) with B = num_negatives = 1 (reference lib.py:572-575); 'sum' over the
-                # group's samples leaves every sample its own gradient
-                _, _, g_aug = ops.ctc_loss(post[:Rn].contiguous(), targets, ilen, tlen, blank, reduction="sum", grad_scale=1.0 / (N * num_negatives))
                 optimizer.zero_grad()
-                model.backward(g_aug, n_active=Rn)
-                optimizer.step()
-                if online:
-                    for r in range(Rn):
-                        stitch_window(r, i, post[Rn + r].detach(), u_len)
+                for (lo, hi), (post, ctx) in zip(classes, posts):
+                    n = hi - lo
+                    target_ids = []
+                    for q in range(lo, hi):
+                        pseudo_targets = tokenizer.decode(pinned[0][q, :int(pinned[1][q])].tolist())
+                        target_ids.append(tokenizer.encode(pseudo_targets))                   # text hop kept (reference lib.py:569)
+                    S_max = max(1, max(len(t) for t in target_ids))
+                    if tgt_ring is None or tgt_ring[0][0].shape[1] < S_max:
+                        tgt_ring = [(torch.zeros(Rn, max(2 * S_max, 256), dtype=torch.int32, pin_memory=True),
+                                     torch.zeros(Rn, dtype=torch.int32, pin_memory=True)) for _ in range(4 * max(1, len(classes)))]
+                    slot, lens = tgt_ring[tgt_turn % len(tgt_ring)]
+                    tgt_turn += 1
+                    for k, t in enumerate(target_ids):
+                        if t:
+                            slot[k, :len(t)] = torch.as_tensor(t, dtype=torch.int32)
+                        lens[k] = len(t)
+                    targets = torch.empty(n, S_max, dtype=torch.int32, device=device)
+                    targets.copy_(slot[:n, :S_max], non_blocking=True)
+                    tlen = torch.empty(n, dtype=torch.int32, device=device)
+                    tlen.copy_(lens[:n], non_blocking=True)
+                    N = post.shape[1]
+                    ilen = torch.full((n,), N, dtype=torch.int32, device=device)
+                    # per recording: CTCLoss(reduction='sum') / (N * B) with B = num_negatives = 1 (reference lib.py:572-575); 'sum' over the
+                    # class's samples leaves every sample its own gradient
+                    _, _, g_aug = ops.ctc_loss(post[:n].contiguous(), targets, ilen, tlen, blank, reduction="sum", grad_scale=1.0 / (N * num_negatives))
+                    model.set_range(lo, hi)
+                    model._ctx, model._ctx_static, model._ctx_key = ctx
+                    model.backward(g_aug, n_active=n)
+                    if online:
+                        for q in range(lo, hi):
+                            stitch_window(q, i, post[n + q - lo].detach(), u_lens[q])
+                optimizer.step(limit=(members[-1] + 1) * n_flat)       # the recordings that had a window at this position (a prefix)
                 if sampled:
                     ops.gemm_profile_end_step(device, sampled)
         if not online:
             model.eval()
-            keys = sorted(data[0].keys())
             idx = 0
-            while idx < len(keys):
-                group = [keys[idx]]
-                u_len = data[0][keys[idx]].shape[-1]
-                while len(group) < final_batch and idx + len(group) < len(keys) and data[0][keys[idx + len(group)]].shape[-1] == u_len:
-                    group.append(keys[idx + len(group)])
+            while idx < len(all_keys):
+                k0 = all_keys[idx]
+                members = [q for q in range(Rn) if k0 in data[q]]
+                u_lens = {q: data[q][k0].shape[-1] for q in members}
+                classes = _shape_classes(members, u_lens)
+                lo, hi = classes[0]                     # the class of the longest recordings: batch consecutive positions of the same class
+                group = [k0]
+                while len(group) < final_batch and idx + len(group) < len(all_keys):
+                    kn = all_keys[idx + len(group)]
+                    mem_n = [q for q in range(Rn) if kn in data[q]]
+                    ul_n = {q: data[q][kn].shape[-1] for q in mem_n}
+                    if not mem_n or _shape_classes(mem_n, ul_n)[0] != (lo, hi) or ul_n[lo] != u_lens[lo]:
+                        break
+                    group.append(kn)
                 sampled = 0
                 if ops.gemm_profile_active():
                     sampled = ops.gemm_profile_begin_step(device)
-                batch = torch.empty(len(group) * Rn, Fq, u_len, device=device, dtype=torch.float32)
+                n = hi - lo
+                batch = torch.empty(len(group) * n, Fq, u_lens[lo], device=device, dtype=torch.float32)
                 for c, k in enumerate(group):
-                    for r in range(Rn):
-                        batch[c * Rn + r].copy_(data[r][k][0])
+                    for q in range(lo, hi):
+                        batch[c * n + q - lo].copy_(data[q][k][0])
+                model.set_range(lo, hi)
                 with torch.no_grad():
                     post = model(audio_signal=batch)['final_posteriors']
                     for c, k in enumerate(group):
-                        for r in range(Rn):
-                            stitch_window(r, k, post[c * Rn + r], u_len)
+                        for q in range(lo, hi):
+                            stitch_window(q, k, post[c * n + q - lo], u_lens[lo])
+                    for k in group:                 # the other classes at these positions (short last windows): one forward each
+                        mem_k = [q for q in range(Rn) if k in data[q] and not (lo <= q < hi)]
+                        ul_k = {q: data[q][k].shape[-1] for q in mem_k}
+                        for l2, h2 in _shape_classes(mem_k, ul_k):
+                            b2 = torch.empty(h2 - l2, Fq, ul_k[l2], device=device, dtype=torch.float32)
+                            for q in range(l2, h2):
+                                b2[q - l2].copy_(data[q][k][0])
+                            model.set_range(l2, h2)
+                            p2 = model(audio_signal=b2)['final_posteriors']
+                            for q in range(l2, h2):
+                                stitch_window(q, k, p2[q - l2], ul_k[l2])
                 idx += len(group)
                 if sampled:
                     ops.gemm_profile_end_step(device, sampled)
                 yield
             model.train()
-        results = []
-        for r in range(Rn):
-            logits_dev = ops.stitch_finalize(acc[r], cnt[r], stitch[r]["end"])
+        for q in range(Rn):
+            logits_dev = ops.stitch_finalize(acc[q], cnt[q], stitch[q]["end"])
             logits = logits_dev if return_device else logits_dev.cpu().numpy()
             if return_params:
-                results.append((logits, [p.clone().detach().cpu() for p in model.replica_params(r)]))
+                results[order[q]] = (logits, [p.clone().detach().cpu() for p in model.replica_params(q)])
             else:
-                results.append(logits)
+                results[order[q]] = logits
     finally:
         model.flat_params[:Rn * n_flat].copy_(original_flat)      # reference lib.py:636-637
         model.grad_samples = None
-        model.active = prev_active
+        model.set_range(*prev_range)
     return results
 
 
@@ -731,9 +789,9 @@ def dynamic_eval_many(args, models, specs, seq_len, overlap, tokenizer, **kw):
         # cover (lockstep_supported) cannot run on a group model at all, so it is refused here rather than silently run differently
         items, k = [], 0
         while k < len(specs):
-            n = 1
-            while n < R and k + n < len(specs) and specs[k + n].shape[-1] == specs[k].shape[-1]:
-                n += 1
+            n = min(R, len(specs) - k)
+            while n > 1 and not lockstep_supported(args, models[0], specs[k:k + n], kw.get('beam_search_fn'), kw.get('optimizer_state')):
+                n -= 1          # e.g. several epochs: only recordings of equal length share a group
             if not lockstep_supported(args, models[0], specs[k:k + n], kw.get('beam_search_fn'), kw.get('optimizer_state')):
                 raise ops.DynError("dynamic_eval_many: these arguments need the one-recording-per-model path (pass ungrouped models)")
             items.append((list(range(k, k + n)), specs[k:k + n]))

@@ -144,7 +144,7 @@ class SCConformerXL:
         self.R = int(group)
         if self.R < 1:
             raise ValueError("group must be >= 1")
-        self.active = self.R        # replicas taking part in the current batches (a last, smaller group of recordings uses the first `active`)
+        self._lo, self._n = 0, self.R   # replicas [lo, lo + n) take part in the current batches (see `active` / set_range)
         cfg = self.config
         if cfg["conv_norm"] not in ("rms_norm", "layer_norm", "batch_renorm"):
             raise ValueError(f"unknown conv_norm {cfg['conv_norm']}")
@@ -218,12 +218,28 @@ class SCConformerXL:
         self.training = False
 
     # ------------------------------------------------------------------ lockstep group helpers
+    @property
+    def active(self):
+        """Number of replicas taking part in the current batches (a batch holds chunks * active samples)."""
+        return self._n
+
+    @active.setter
+    def active(self, n):
+        self.set_range(0, n)
+
+    def set_range(self, lo, hi):
+        """Batches from now on belong to replicas lo .. hi-1 (sample s -> replica lo + s % (hi - lo)): a group whose recordings have
+        different lengths runs its full windows on a shrinking prefix and every short last window on the replica that owns it."""
+        if not (0 <= lo < hi <= self.R):
+            raise ops.DynError(f"replica range [{lo}, {hi}) outside the group of {self.R}")
+        self._lo, self._n = int(lo), int(hi - lo)
+
     def _w(self, name):
         """The parameter as the kernels take it: the tensor itself, or (R > 1) the group view with its replica stride."""
-        return self.P[name] if self.R == 1 else ops.GroupParam(self.PR[name][:self.active], self.active, self.n_flat)
+        return self.P[name] if self.R == 1 else ops.GroupParam(self.PR[name][self._lo:self._lo + self._n], self._n, self.n_flat)
 
     def _gw(self, name):
-        return self.G[name] if self.R == 1 else ops.GroupParam(self.GR[name][:self.active], self.active, self.n_flat)
+        return self.G[name] if self.R == 1 else ops.GroupParam(self.GR[name][self._lo:self._lo + self._n], self._n, self.n_flat)
 
     def replica_params(self, r):
         """Views of replica r's parameters, in named_parameters() order."""
@@ -238,8 +254,8 @@ class SCConformerXL:
 
     def parameters(self):
         pl = ParamList(self.P[n] for n, _ in self.spec)
-        n = self.active * self.n_flat         # a lockstep group steps its active replicas' buffers in one launch
-        pl.flat_params, pl.flat_grads = self.flat_params[:n], self.flat_grads[:n]
+        lo, hi = self._lo * self.n_flat, (self._lo + self._n) * self.n_flat      # a lockstep group steps its active replicas' buffers in one launch
+        pl.flat_params, pl.flat_grads = self.flat_params[lo:hi], self.flat_grads[lo:hi]
         return pl
 
     def grads(self):
@@ -342,7 +358,10 @@ class SCConformerXL:
         R = self.active
         if dy.shape[0] != R:
             raise ops.DynError(f"lockstep group: the backward runs on one sample per replica (got a batch of {dy.shape[0]} for {R} replicas)")
-        GR = self.GR
+        lo = self._lo
+        GR = {wname: self.GR[wname][lo:lo + R]}
+        if bname is not None:
+            GR[bname] = self.GR[bname][lo:lo + R]
         shared = wname in ("decoder.ff.weight", "decoder.reproj.weight") and self.stack_shared_wgrads and alpha == 1.0
         block_local = wname.startswith("layers.") or wname == "subsampling.out.weight"      # the deep-K subsampling products stay immediate (split-K)
         if wg and self._wq is not None and (block_local or shared) and ops.wgrad_groupable(dy[0], x[0], GR[wname][0]):
@@ -353,7 +372,7 @@ class SCConformerXL:
                         cap = self.config["n_layers"] + 1
                         sh = {"w": torch.empty(cap, *GR[wname][r].shape, device=self.device, dtype=torch.float32),
                               "b": torch.empty(cap, GR[bname][r].numel(), device=self.device, dtype=torch.float32) if bg else None, "bname": bname, "k": 0,
-                              "wname": wname, "r": r}
+                              "wname": wname, "r": lo + r}
                         self._shared[(wname, r)] = sh
                     k = sh["k"]
                     sh["k"] = k + 1
@@ -422,7 +441,7 @@ class SCConformerXL:
             return self._forward_eager(x)
         G = self._graphs
         key = (tuple(x.shape), torch.is_grad_enabled(), self.fused_convmod, self.fused_attention, self.fused_silu, str(self.fused_attention_grad),
-               self.fused_subsampling, self.grad_samples, self.active)
+               self.fused_subsampling, self.grad_samples, self._lo, self._n)
         ent = G["fwd"].get(key)
         if ent is None:
             G["seen"][key] = G["seen"].get(key, 0) + 1
@@ -470,7 +489,7 @@ class SCConformerXL:
             u2 = torch.empty(B, ops.out_len(ops.out_len(T)), ops.out_len(ops.out_len(Fq)), C, device=x.device, dtype=torch.float32)
             PR = self.PR
             for k in range(B):
-                r = k % R
+                r = self._lo + k % R
                 ops.sub12_fwd(xt[k:k + 1], PR["subsampling.conv1.weight"][r], PR["subsampling.conv1.bias"][r], PR["subsampling.dw2.weight"][r],
                               PR["subsampling.dw2.bias"][r], out=u2[k:k + 1])
         elif self.fused_subsampling:
@@ -483,7 +502,7 @@ class SCConformerXL:
         if grp:
             u3 = torch.empty(B, ops.out_len(z2.shape[1]), ops.out_len(z2.shape[2]), C, device=x.device, dtype=torch.float32)
             for k in range(B):
-                ops.dwconv2d_s2(z2[k:k + 1], self.PR["subsampling.dw3.weight"][k % R], self.PR["subsampling.dw3.bias"][k % R], out=u3[k:k + 1])
+                ops.dwconv2d_s2(z2[k:k + 1], self.PR["subsampling.dw3.weight"][self._lo + k % R], self.PR["subsampling.dw3.bias"][self._lo + k % R], out=u3[k:k + 1])
         else:
             u3 = ops.dwconv2d_s2(z2, P["subsampling.dw3.weight"], P["subsampling.dw3.bias"])
         if self.fused_silu:
@@ -493,6 +512,9 @@ class SCConformerXL:
             z3 = ops.linear(u3, W("subsampling.pw3.weight"), W("subsampling.pw3.bias"))
             a3 = ops.silu(z3)
         T3, F3 = a3.shape[1], a3.shape[2]
+        if grp and save and R > 1 and (T3 * self.num_classes) % 4:
+            raise ops.DynError(f"lockstep group: T' x (V + 1) = {T3} x {self.num_classes} must be a multiple of 4 (the backward takes per-replica "
+                               "slices of the head's tensors with 16-byte vector accesses)")
         h = ops.linear(a3.view(B, T3, F3 * C), W("subsampling.out.weight"), W("subsampling.out.bias"))
         if save:
             ctx["sub"] = (xt, z1, u2, z2, u3, z3, a3)
@@ -814,8 +836,9 @@ class SCConformerXL:
             dg = torch.empty_like(dc)
             for r in range(dc.shape[0]):
                 if self.trainable(p + ".dw.weight") and not self._skip_wgrad:
-                    ops.dwconv1d_wgrad(g[r:r + 1], dc[r:r + 1], self.GR[p + ".dw.weight"][r % self.active], self.GR[p + ".dw.bias"][r % self.active], beta=1.0)
-                ops.dwconv1d_dgrad(dc[r:r + 1], self.PR[p + ".dw.weight"][r % self.active], out=dg[r:r + 1])
+                    ops.dwconv1d_wgrad(g[r:r + 1], dc[r:r + 1], self.GR[p + ".dw.weight"][self._lo + r % self.active],
+                                       self.GR[p + ".dw.bias"][self._lo + r % self.active], beta=1.0)
+                ops.dwconv1d_dgrad(dc[r:r + 1], self.PR[p + ".dw.weight"][self._lo + r % self.active], out=dg[r:r + 1])
             du = ops.glu_bwd(u, dg)
             dn = self._lin_bwd(du, n, p + ".pw1.weight", p + ".pw1.bias")
             return self._res_norm_bwd(h, p + ".norm.weight", p + ".norm.bias", mean, rstd, dn, dh)
@@ -843,14 +866,14 @@ class SCConformerXL:
             PR, GR = self.PR, self.GR
             dz2 = torch.empty_like(z2)
             for r in range(B):
-                q = r % self.active
+                q = self._lo + r % self.active
                 if wg:
                     ops.dwconv2d_s2_wgrad(z2[r:r + 1], du3[r:r + 1], GR["subsampling.dw3.weight"][q], GR["subsampling.dw3.bias"][q], beta=1.0)
                 ops.dwconv2d_s2_dgrad(z2[r:r + 1], PR["subsampling.dw3.weight"][q], du3[r:r + 1], out=dz2[r:r + 1])
             du2 = self._lin_bwd(dz2, u2, "subsampling.pw2.weight", "subsampling.pw2.bias")
             if wg:
                 for r in range(B):
-                    q = r % self.active
+                    q = self._lo + r % self.active
                     ops.sub12_bwd(xt[r:r + 1], du2[r:r + 1], PR["subsampling.conv1.weight"][q], PR["subsampling.conv1.bias"][q],
                                   PR["subsampling.dw2.weight"][q], GR["subsampling.conv1.weight"][q], GR["subsampling.conv1.bias"][q],
                                   GR["subsampling.dw2.weight"][q], GR["subsampling.dw2.bias"][q], beta=1.0)

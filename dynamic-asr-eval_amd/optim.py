@@ -76,11 +76,15 @@ class MADGRAD(_FlatOptimizer):
             raise ValueError(f"Learning rate {lr} must be positive")
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, eps=eps))
 
-    def step(self):
+    def step(self, limit=None):
+        """`limit` (flat-buffer models only): step just the first `limit` elements — the replicas of a lockstep group that are still
+        adapting; a finished recording's weights must not keep drifting towards its dual-averaged iterate."""
         d = self.defaults
         pairs = self._iter_pairs()
         self._alloc_state(pairs, 3)
         for (p, g), (s, nu, x0) in zip(pairs, self.state):
+            if limit is not None:
+                p, g, s, nu, x0 = p[:limit], g[:limit], s[:limit], nu[:limit], x0[:limit]
             ops.madgrad_step(p, g, s, nu, x0, d["lr"], d["momentum"], d["weight_decay"], d["eps"], self.k)
         self.k += 1
 
@@ -89,10 +93,12 @@ class Adam(_FlatOptimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
 
-    def step(self):
+    def step(self, limit=None):
         d = self.defaults
         pairs = self._iter_pairs()
         self._alloc_state(pairs, 2)
         for (p, g), (m, v) in zip(pairs, self.state):
+            if limit is not None:
+                p, g, m, v = p[:limit], g[:limit], m[:limit], v[:limit]
             ops.adam_step(p, g, m, v, d["lr"], d["betas"][0], d["betas"][1], d["eps"], d["weight_decay"], self.k)
         self.k += 1

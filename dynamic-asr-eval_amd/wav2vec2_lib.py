@@ -5,8 +5,11 @@
 Same call signatures; `model` is this package's Wav2Vec2ForCTC (wav2vec2_model.py), `processor` may be None: the only
 thing the reference uses it for is `processor.feature_extractor(...)` = zero-mean / unit-variance normalisation of each
 waveform (eps 1e-7), which runs here as a HIP kernel on the device (dyn_colnorm_fwd with one channel).
-The WavAugment effects of the chunked variant (`augment.EffectChain`, un-vendored and absent; lib.py:131-143) are not
-available: the chunked loop runs with clean copies, as the per-utterance variant does in the reference itself."""
+The WavAugment chain the chunked variant applies to its first copies (`augment.EffectChain`, lib.py:144-156; the package is un-vendored
+and absent) is restated from the published effects as far as it needs no external tool: 100 x `time_dropout(0.1 s)` and the zero-noise
+`additive_noise(snr=0)` run on the device (`wav_augment_chunk`; `-kwargs`-style switch `args.wav_augment=False` turns it off); the
+chain's last effect, `.reverb(50, 50, 100)`, is a sox effect and is not reproduced (parity unpinned).  The per-utterance variant builds
+its effect chains without applying them (lib.py:391-412), so its copies are clean in the reference too."""
 import random
 from types import SimpleNamespace
 
@@ -54,6 +57,35 @@ def normalize_waveform(x):
     zeros = torch.zeros(1, device=x.device, dtype=torch.float32)
     y, _, _ = ops.colnorm(x.contiguous().view(B, L, 1), ones, zeros, eps=1e-7)
     return y.view(B, L)
+
+
+def time_dropout_draws(n_samples, n_rounds=100, max_seconds=0.1, rate=16000):
+    """The (start, length) pairs of `n_rounds` applications of WavAugment's `EffectChain().time_dropout(max_seconds)` to a waveform of
+    `n_samples` samples (reference wav2vec2/lib.py:145,154-155: `for _ in range(100): augmentation_1.apply(...)`).  `augment`
+    (facebookresearch/WavAugment) is un-vendored; its TimeDropout is restated from the published effect: `length = np.random.randint(0,
+    max_frames)`, `start = np.random.randint(0, max(1, n - length))`, the span is zeroed; max_frames = int(rate * max_seconds).
+    PARITY UNPINNED against the upstream package (no fixture); host numpy RNG as upstream, so `np.random.seed` reproduces a run."""
+    import numpy as np
+    max_frames = int(rate * max_seconds)
+    starts, lengths = [], []
+    for _ in range(n_rounds):
+        length = int(np.random.randint(0, max_frames))
+        start = int(np.random.randint(0, max(1, n_samples - length)))
+        starts.append(start); lengths.append(length)
+    return starts, lengths
+
+
+def wav_augment_chunk(wave_row):
+    """The reference's WavAugment chain on one copy [L] of a waveform window, in place on the device (wav2vec2/lib.py:144-156): 100 x
+    time_dropout(0.1 s), then `additive_noise(zeros, snr=0)` = 0.5 * x (WavAugment mixes r / (1 + r) * x + 1 / (1 + r) * noise with r =
+    10^(snr / 10) = 1; the scale survives the feature extractor's normalisation only through its 1e-7 epsilon).  NOT applied: `.reverb(50,
+    50, 100)` — a sox effect; neither WavAugment nor sox exists here and the reference holds no output of it (parity unpinned, stated)."""
+    starts, lengths = time_dropout_draws(wave_row.numel())
+    t0 = torch.tensor(starts, dtype=torch.int32, device=wave_row.device)
+    wd = torch.tensor(lengths, dtype=torch.int32, device=wave_row.device)
+    ops.specaug_timemask(wave_row.view(1, -1), t0, wd, 0.0)
+    ops.axpby(wave_row, wave_row, a=0.0, b=0.5)
+    return wave_row
 
 
 def _snapshot(model):
@@ -138,7 +170,10 @@ def dynamic_eval_ctc_loss(args, model, spec, seq_len, overlap, tokenizer, proces
         for i in (tqdm(keys) if use_tqdm else keys):
             chunk = training_data[i]
             u_len = chunk.shape[-1]
-            audio = chunk.reshape(1, -1).repeat(num_negatives + 1, 1).contiguous()              # clean copies (see module doc)
+            audio = chunk.reshape(1, -1).repeat(num_negatives + 1, 1).contiguous()
+            if args.__dict__.get('wav_augment', True):                                          # lib.py:144-156 on the first copies
+                for j in range(num_negatives):
+                    wav_augment_chunk(audio[j])
             input_values = normalize_waveform(audio)
             with torch.enable_grad():
                 logits = model(input_values).logits

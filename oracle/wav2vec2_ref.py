@@ -48,7 +48,21 @@ def dynamic_eval_su_ref(args, model, utterances, tokenizer, optimizer_cls, num_n
     return utterances
 
 
-def dynamic_eval_chunked_ref(args, model, spec, seq_len, overlap, tokenizer, optimizer_cls, num_negatives=1, lr_args=None):
+def wav_augment_ref(x, n_rounds=100, max_seconds=0.1, rate=16000):
+    """x [1, L]: 100 x WavAugment time_dropout(0.1 s) (zero a span of np.random.randint(0, 1600) samples starting at
+    np.random.randint(0, max(1, L - length))), then additive_noise(zero noise, snr=0) = 0.5 * x (reference wav2vec2/lib.py:144-156).  `augment`
+    is un-vendored (restated from the published effects, PARITY UNPINNED); the chain's last effect, `.reverb(50, 50, 100)` (sox), is not
+    reproduced on either side."""
+    import numpy as np
+    max_frames = int(rate * max_seconds)
+    for _ in range(n_rounds):
+        length = int(np.random.randint(0, max_frames))
+        start = int(np.random.randint(0, max(1, x.shape[-1] - length)))
+        x[:, start:start + length] = 0.0
+    return x * 0.5
+
+
+def dynamic_eval_chunked_ref(args, model, spec, seq_len, overlap, tokenizer, optimizer_cls, num_negatives=1, lr_args=None, wav_augment=True):
     """reference wav2vec2/lib.py:41-235 on the transformers CPU model, statement by statement:
     downsampling_factor hard-coded 4 (:59), snapshot (:63-64), CTCLoss(blank, reduction='sum') (:66), fresh optimiser (:98),
     `seq_len > spec_n` rule (:104-105), overlap % 4 assert (:107), accumulators of spec_n // 4 + seq_len rows (:110), the inlined
@@ -56,9 +70,8 @@ def dynamic_eval_chunked_ref(args, model, spec, seq_len, overlap, tokenizer, opt
     normalisation (:161), forward of all copies but the last (:163), log_softmax (:169), greedy pseudo-label of log_p[-1] (:170),
     tokenise (:174), CTC of the first num_negatives copies / (N * B) (:177-181), zero_grad / backward / step (:193-197), keep
     exp(log_p[-1]) with ds_len and overlap_ds = int(overlap / (u_len / ds_len)) (:205-210); stitch (:214-230); restore (:233-234).
-    NOT reproduced: the WavAugment effect chains applied to the first copies (:144-156; `augment` = facebookresearch/WavAugment is
-    un-vendored and absent) — the copies stay clean, as they do in the reference's own per-utterance variant (PARITY UNPINNED
-    for that augmentation)."""
+    The WavAugment chain on the first copies (:144-156): 100 x time_dropout(0.1 s) and additive_noise(zeros, snr=0) are restated
+    (`wav_augment_ref`; `augment` = facebookresearch/WavAugment is un-vendored: PARITY UNPINNED), `.reverb(50, 50, 100)` (sox) is not."""
     from .dynamic_eval_ref import stitch_ref
     spec_n = spec.shape[-1]
     downsampling_factor = 4
@@ -89,6 +102,9 @@ def dynamic_eval_chunked_ref(args, model, spec, seq_len, overlap, tokenizer, opt
         for i in training_keys:
             audio_chunk = training_data[i].clone()
             audio_chunk = audio_chunk.repeat(num_negatives + 2, 1, 1).contiguous()
+            if wav_augment:
+                for j in range(num_negatives):
+                    audio_chunk[j] = wav_augment_ref(audio_chunk[j])
             u_len = audio_chunk.shape[-1]
             audio_chunk = audio_chunk.squeeze(1)
             input_values = normalize_waveform(audio_chunk)

@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--spec_seed", type=int, default=77)
     ap.add_argument("--mask_seed", type=int, default=9)
     ap.add_argument("--blank_bias", type=float, default=1.34)
+    ap.add_argument("--init", default="oracle", choices=["oracle", "synthetic"], help="synthetic: bench.py's weights (synthetic_weights.init_synthetic "
+                    "seed 0 + the blank bias) instead of the oracle's seeded initialisation")
     ap.add_argument("--label_tokens", type=int, default=0, help="> 0: tokenizer.encode returns this many fixed seeded ids per window on BOTH sides "
                     "(bench.py's SubstituteLabelTokenizer): a seeded model's own labels collapse to blank after a few steps, this keeps every "
                     "carried step on a speech-like lattice (|alpha| in the thousands)")
@@ -161,7 +163,13 @@ def main():
     dev = torch.device("cuda:0")
     ref = SCConformerXLRef(vocab_size=VOCAB, seed=0, blank_bias=a.blank_bias)
     hip = SCConformerXL(vocab_size=VOCAB, device=dev)
-    hip.load_state_dict(ref.state_dict())
+    if a.init == "synthetic":
+        from dynamic_asr_eval_amd.synthetic_weights import init_synthetic
+        init_synthetic(hip, seed=0, blank_bias=0.0)
+        hip.P["decoder.ff.bias"][-1] += a.blank_bias
+        ref.load_state_dict({k: v.cpu() for k, v in hip.state_dict().items()})
+    else:
+        hip.load_state_dict(ref.state_dict())
     tok = SyntheticTokenizer(VOCAB)
 
     def logged(log_tok):

@@ -573,7 +573,7 @@ def test_lockstep_group_matches_separate_models(cuda):
     arithmetic), eager and through the hipGraph replay, and with fewer active replicas than the group holds."""
     from dynamic_asr_eval_amd.model import SCConformerXL
     from oracle.conformer_ref import SCConformerXLRef
-    R, T = 3, 300
+    R, T = 3, 320          # T' = 40: per-replica slices of the [R, T', 129] head tensors stay 16-byte aligned
     refs = [SCConformerXLRef(SMALL, vocab_size=128, seed=40 + r, blank_bias=0.5) for r in range(R)]
     singles = []
     for ref in refs:
@@ -611,7 +611,7 @@ def test_lockstep_group_matches_separate_models(cuda):
     gl = (torch.randn(R, Tp, 129, generator=g) / (Tp * 129)).to(cuda)
     for r, m in enumerate(singles):
         m.zero_grad()
-        m.backward(gl[r:r + 1].contiguous(), n_active=1)
+        m.backward(gl[r:r + 1].clone(), n_active=1)          # a fresh (16-byte aligned) buffer: the slice of an odd-sized tensor is not
         grads.append(m.flat_grads.clone())
     for active, use_graphs, reps in ((R, False, 1), (R, True, 3), (2, False, 1), (1, True, 3)):
         og, gg = run_group(active, use_graphs, reps)
@@ -669,3 +669,25 @@ def test_lockstep_dynamic_eval_matches_one_recording_at_a_time(cuda):
                 assert np.array_equal(o.argmax(-1), ow.argmax(-1))
                 for x, y in zip(p, pw):
                     assert (x - y).abs().max().item() < 5e-5
+    # recordings of DIFFERENT lengths in one group (given out of length order): the full windows run on the longer ones together, each short
+    # last window on its own replica, a finished recording's replica is no longer stepped
+    lens = (1100, 1500, 1360)
+    specs2 = [torch.randn(1, 80, n, generator=g) for n in lens]
+    masks2 = [_masks_for(range(0, 2048, 256), 80, None, seed=50 + r) for r in range(R)]
+    for online in (False, True):
+        want = []
+        for r in range(R):
+            a = _args(optim_lr=1e-4, epochs=1, shuffle=False, online=online, spec_augment_fixed_masks=masks2[r], quiet=True)
+            want.append(lib.dynamic_eval(a, single, specs2[r], 512, 256, tok, use_tqdm=False, return_params=True))
+        a = _args(optim_lr=1e-4, epochs=1, shuffle=False, online=online, spec_augment_fixed_masks=masks2, quiet=True)
+        before = grp.flat_params.clone()
+        got = lib.dynamic_eval_lockstep(a, grp, specs2, 512, 256, tok, use_tqdm=False, return_params=True)
+        assert torch.equal(grp.flat_params, before)
+        for r in range(R):
+            (o, p), (ow, pw) = got[r], want[r]
+            assert o.shape == ow.shape and np.abs(o - ow).max() < 2e-4, (online, r, o.shape, ow.shape, np.abs(o - ow).max())
+            assert np.array_equal(o.argmax(-1), ow.argmax(-1))
+            for x, y in zip(p, pw):
+                assert (x - y).abs().max().item() < 5e-5
+    a = _args(optim_lr=1e-4, epochs=2, shuffle=False, spec_augment_fixed_masks=masks2, quiet=True)
+    assert not lib.lockstep_supported(a, grp, specs2) and lib.lockstep_supported(a, grp, specs)      # several epochs: equal lengths only

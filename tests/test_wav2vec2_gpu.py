@@ -155,11 +155,25 @@ def test_chunked_dynamic_eval_matches_oracle(cuda, seq_len, overlap, epochs, L):
     wav = torch.randn(1, L, generator=torch.Generator().manual_seed(L + overlap)) * 0.1 + 0.01
     args = argparse.Namespace(epochs=epochs, shuffle=False)
     before = hip.flat_params.clone()
+    # r04: the first copy goes through the WavAugment chain of wav2vec2/lib.py:144-156 (100 x time_dropout(0.1 s) + the zero-noise
+    # additive_noise = 0.5 x; draws from np.random as upstream): the same seed on both sides gives the same dropped spans
+    np.random.seed(1000 + L)
     want = dynamic_eval_chunked_ref(args, ref, wav, seq_len, overlap, tok, MADGRAD_REF, lr_args={'lr': 1e-5})
+    np.random.seed(1000 + L)
     got = W.dynamic_eval(args, hip, wav, seq_len, overlap, tok, None, use_tqdm=False, optim=W.MADGRAD, lr_args={'lr': 1e-5})
     assert torch.equal(hip.flat_params, before)
     assert got.shape == want.shape, (got.shape, want.shape)
     assert np.abs(got - want).max() < 1e-3 and np.array_equal(got.argmax(-1), want.argmax(-1))
+    if L == 15000 and overlap == 0:      # the augmentation is really applied: without it the result moves, and the device masking = the host's
+        from oracle.wav2vec2_ref import wav_augment_ref
+        np.random.seed(5)
+        host = wav_augment_ref(wav[:, :6000].clone())
+        np.random.seed(5)
+        dev = W.wav_augment_chunk(wav[0, :6000].clone().to(cuda)).cpu()
+        assert torch.equal(dev, host[0]) and int((host == 0).sum()) > 1000
+        np.random.seed(1000 + L)
+        clean = dynamic_eval_chunked_ref(args, ref, wav, seq_len, overlap, tok, MADGRAD_REF, lr_args={'lr': 1e-5}, wav_augment=False)
+        assert np.abs(clean - want).max() > 1e-6
 
 
 def test_chunked_dynamic_eval_at_the_reference_window(cuda, base_pair):
@@ -174,7 +188,9 @@ def test_chunked_dynamic_eval_at_the_reference_window(cuda, base_pair):
     tok = W.CharTokenizer()
     wav = torch.randn(1, 150000, generator=torch.Generator().manual_seed(3)) * 0.1
     args = argparse.Namespace(epochs=1, shuffle=False)
+    np.random.seed(77)
     want = dynamic_eval_chunked_ref(args, ref, wav, 131072, 0, tok, MADGRAD_REF, lr_args={'lr': 1e-6})
+    np.random.seed(77)
     got = W.dynamic_eval(args, hip, wav, 131072, 0, tok, None, use_tqdm=False, optim=W.MADGRAD, lr_args={'lr': 1e-6})
     assert got.shape == want.shape == (409 + 58, 32) and np.isfinite(want).all(), "the oracle itself must produce a finite result"
     err = np.abs(got - want).max()
