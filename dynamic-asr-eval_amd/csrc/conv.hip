@@ -23,11 +23,16 @@ constexpr int TT = 32;  // time steps per workgroup tile
 template <int KW, bool FLIP>
 __global__ __launch_bounds__(256) void dwconv1d_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int64_t T,
-                                                        int C, float beta) {
+                                                        int C, float beta, int ngroups, int64_t pstride) {
     constexpr int P = (KW - 1) / 2;
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= C) return;
     const int64_t b = blockIdx.z;
+    {   // lockstep group: sample b convolves with the filters of replica b % ngroups (ngroups = 1: plain launch)
+        const int64_t poff = (int64_t)(blockIdx.z % ngroups) * pstride;
+        w += poff;
+        if (bias) bias += poff;
+    }
     const int64_t t0 = (int64_t)blockIdx.x * TT;
     float wk[KW];
 #pragma unroll
@@ -718,9 +723,9 @@ __global__ __launch_bounds__(256) void dwconv2d_s2_wgrad_kernel(const float* __r
 
 template <bool FLIP>
 int launch_dw1d(const float* x, const float* w, const float* bias, float* y, int64_t B, int64_t T, int64_t C, int64_t KW,
-                float beta, hipStream_t st) {
+                float beta, hipStream_t st, int ngroups = 1, int64_t pstride = 0) {
     dim3 grid((unsigned)dyn::cdiv(T, TT), (unsigned)dyn::cdiv(C, 256), (unsigned)B), blk(256);
-#define GO(K) hipLaunchKernelGGL((dwconv1d_kernel<K, FLIP>), grid, blk, 0, st, x, w, bias, y, T, (int)C, beta)
+#define GO(K) hipLaunchKernelGGL((dwconv1d_kernel<K, FLIP>), grid, blk, 0, st, x, w, bias, y, T, (int)C, beta, ngroups, pstride)
     switch (KW) {
         case 3: GO(3); break; case 5: GO(5); break; case 7: GO(7); break; case 9: GO(9); break;
         case 15: GO(15); break; case 31: GO(31); break;
@@ -765,14 +770,36 @@ extern "C" int dyn_dwconv1d_dgrad(const float* dy, const float* w, float* dx, in
     return launch_dw1d<true>(dy, w, nullptr, dx, B, T, C, KW, dx_beta, (hipStream_t)stream);
 }
 
+// lockstep-group variants (see dyn_layernorm_fwd_g, include/dyneval.h): sample b uses / accumulates into the filters of replica b % n_groups
+extern "C" int dyn_dwconv1d_dgrad_g(const float* dy, const float* w, float* dx, int64_t B, int64_t T, int64_t C, int64_t KW, float dx_beta,
+                                    int64_t n_groups, int64_t param_stride, void* stream) {
+    DYN_REQUIRE(dy && w && dx && B >= 0 && T >= 0 && C > 0 && n_groups >= 1 && B % n_groups == 0, DYN_E_ARG, "dyn_dwconv1d_dgrad_g: bad arguments");
+    if (B == 0 || T == 0) return DYN_OK;
+    return launch_dw1d<true>(dy, w, nullptr, dx, B, T, C, KW, dx_beta, (hipStream_t)stream, (int)n_groups, param_stride);
+}
+
 extern "C" int64_t dyn_dwconv1d_wgrad_workspace_bytes(int64_t B, int64_t T, int64_t C, int64_t KW) {
     int64_t per;
     const int64_t tiles = wgrad_tiles(B, T, &per) * B;
     return tiles * C * (KW + 1) * (int64_t)sizeof(float);
 }
 
+static int dwconv1d_wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, float beta, int64_t B, int64_t T, int64_t C, int64_t KW,
+                              void* workspace, int64_t workspace_bytes, int64_t n_groups, int64_t pstride, void* stream);
+
 extern "C" int dyn_dwconv1d_wgrad(const float* x, const float* dy, float* dw, float* dbias, float beta, int64_t B, int64_t T,
                                   int64_t C, int64_t KW, void* workspace, int64_t workspace_bytes, void* stream) {
+    return dwconv1d_wgrad_impl(x, dy, dw, dbias, beta, B, T, C, KW, workspace, workspace_bytes, 1, 0, stream);
+}
+
+extern "C" int dyn_dwconv1d_wgrad_g(const float* x, const float* dy, float* dw, float* dbias, float beta, int64_t B, int64_t T, int64_t C,
+                                    int64_t KW, int64_t n_groups, int64_t param_stride, void* workspace, int64_t workspace_bytes, void* stream) {
+    DYN_REQUIRE(n_groups >= 1 && B % n_groups == 0, DYN_E_ARG, "dyn_dwconv1d_wgrad_g: the batch must hold whole chunks of n_groups samples");
+    return dwconv1d_wgrad_impl(x, dy, dw, dbias, beta, B, T, C, KW, workspace, workspace_bytes, n_groups, param_stride, stream);
+}
+
+static int dwconv1d_wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, float beta, int64_t B, int64_t T, int64_t C, int64_t KW,
+                              void* workspace, int64_t workspace_bytes, int64_t n_groups, int64_t pstride, void* stream) {
     DYN_REQUIRE(x && dy && dw && B >= 0 && T >= 0 && C > 0, DYN_E_ARG, "dyn_dwconv1d_wgrad: bad arguments");
     if (B == 0 || T == 0) return DYN_OK;
     int64_t per;
@@ -790,8 +817,17 @@ extern "C" int dyn_dwconv1d_wgrad(const float* x, const float* dy, float* dw, fl
         default: dyn::set_error("dwconv1d_wgrad: unsupported kernel width %lld", (long long)KW); return DYN_E_UNSUPPORTED;
     }
 #undef GO
-    dyn::reduce_or_defer(pw, dw, tiles, C * KW, beta, st);
-    if (dbias) dyn::reduce_or_defer(pb, dbias, tiles, C, beta, st);
+    if (n_groups <= 1) {
+        dyn::reduce_or_defer(pw, dw, tiles, C * KW, beta, st);
+        if (dbias) dyn::reduce_or_defer(pb, dbias, tiles, C, beta, st);
+    } else {        // a sample's tiles are contiguous (tile = b * chunks + chunk): one reduction per sample into its replica's gradient
+        for (int64_t b = 0; b < B; ++b) {
+            const int64_t po = (b % n_groups) * pstride;
+            const float wb = b < n_groups ? beta : 1.f;
+            dyn::reduce_or_defer(pw + b * chunks * C * KW, dw + po, chunks, C * KW, wb, st);
+            if (dbias) dyn::reduce_or_defer(pb + b * chunks * C, dbias + po, chunks, C, wb, st);
+        }
+    }
     return dyn::check_launch("dyn_dwconv1d_wgrad");
 }
 

@@ -18,11 +18,17 @@ __global__ __launch_bounds__(TPB) void convmod_fwd_kernel(const float* __restric
                                                           const float* __restrict__ beta, float* __restrict__ s_out,
                                                           float* __restrict__ g_out, float* __restrict__ c_out, float* __restrict__ nn_out,
                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t T,
-                                                          float eps) {
+                                                          float eps, int ngroups, int64_t pstride) {
     constexpr int C = NV * 256;
     __shared__ float red[2][4][TT];
     __shared__ float stat[2][TT];
     const int64_t b = blockIdx.y;
+    {   // lockstep group: sample b takes the parameters of replica b % ngroups, pstride elements apart (ngroups = 1: plain launch)
+        const int64_t poff = (int64_t)(blockIdx.y % ngroups) * pstride;
+        w += poff; gamma += poff;
+        if (bias) bias += poff;
+        if (beta) beta += poff;
+    }
     const int64_t t0 = (int64_t)blockIdx.x * TT;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float cv[NV][TT];
@@ -101,15 +107,34 @@ __global__ __launch_bounds__(TPB) void convmod_fwd_kernel(const float* __restric
 
 // layernorm == 0: RMSNorm (beta ignored, mean_out unused); g_out / c_out / nn_out (= norm output) / mean_out / rstd_out may
 // be NULL (no-grad pass).
+static int convmod_launch(const float* u, const float* w, const float* bias, const float* gamma, const float* beta, float* s,
+                          float* g_out, float* c_out, float* nn_out, float* mean_out, float* rstd_out, int64_t B, int64_t T, int64_t C,
+                          int64_t KWIDTH, int32_t layernorm, float eps, int ngroups, int64_t pstride, void* stream);
+
 extern "C" int dyn_convmod_fwd(const float* u, const float* w, const float* bias, const float* gamma, const float* beta, float* s,
                                float* g_out, float* c_out, float* nn_out, float* mean_out, float* rstd_out, int64_t B, int64_t T, int64_t C,
                                int64_t KWIDTH, int32_t layernorm, float eps, void* stream) {
+    return convmod_launch(u, w, bias, gamma, beta, s, g_out, c_out, nn_out, mean_out, rstd_out, B, T, C, KWIDTH, layernorm, eps, 1, 0, stream);
+}
+
+// lockstep-group variant: sample b of the batch uses the parameters of replica b % n_groups, param_stride elements apart
+extern "C" int dyn_convmod_fwd_g(const float* u, const float* w, const float* bias, const float* gamma, const float* beta, float* s,
+                                 float* g_out, float* c_out, float* nn_out, float* mean_out, float* rstd_out, int64_t B, int64_t T, int64_t C,
+                                 int64_t KWIDTH, int32_t layernorm, float eps, int64_t n_groups, int64_t param_stride, void* stream) {
+    DYN_REQUIRE(n_groups >= 1 && B % n_groups == 0, DYN_E_ARG, "dyn_convmod_fwd_g: the batch must hold whole chunks of n_groups samples");
+    return convmod_launch(u, w, bias, gamma, beta, s, g_out, c_out, nn_out, mean_out, rstd_out, B, T, C, KWIDTH, layernorm, eps, (int)n_groups,
+                          param_stride, stream);
+}
+
+static int convmod_launch(const float* u, const float* w, const float* bias, const float* gamma, const float* beta, float* s,
+                          float* g_out, float* c_out, float* nn_out, float* mean_out, float* rstd_out, int64_t B, int64_t T, int64_t C,
+                          int64_t KWIDTH, int32_t layernorm, float eps, int ngroups, int64_t pstride, void* stream) {
     DYN_REQUIRE(u && w && gamma && s && B >= 0 && T >= 0 && C > 0, DYN_E_ARG, "dyn_convmod_fwd: bad arguments");
     DYN_REQUIRE(KWIDTH == KW && C % 256 == 0 && C <= 1024, DYN_E_UNSUPPORTED, "dyn_convmod_fwd: needs kernel width 9 and C in {256,512,768,1024}");
     if (B == 0 || T == 0) return DYN_OK;
     dim3 grid((unsigned)dyn::cdiv(T, TT), (unsigned)B), blk(TPB);
     hipStream_t st = (hipStream_t)stream;
-#define GO(NV, LN) hipLaunchKernelGGL((convmod_fwd_kernel<NV, LN>), grid, blk, 0, st, u, w, bias, gamma, beta, s, g_out, c_out, nn_out, mean_out, rstd_out, T, eps)
+#define GO(NV, LN) hipLaunchKernelGGL((convmod_fwd_kernel<NV, LN>), grid, blk, 0, st, u, w, bias, gamma, beta, s, g_out, c_out, nn_out, mean_out, rstd_out, T, eps, ngroups, pstride)
     const int nv = (int)(C / 256);
     if (layernorm) { if (nv == 1) GO(1, true); else if (nv == 2) GO(2, true); else if (nv == 3) GO(3, true); else GO(4, true); }
     else { if (nv == 1) GO(1, false); else if (nv == 2) GO(2, false); else if (nv == 3) GO(3, false); else GO(4, false); }

@@ -832,13 +832,10 @@ class SCConformerXL:
         else:
             ops.layernorm_bwd(c, self._w(p + ".cnorm.weight"), stats[0], stats[1], dnn, dc, self._gw(p + ".cnorm.weight"),
                               self._gw(p + ".cnorm.bias"), dx_beta=0.0)
-        if self.R > 1:          # depthwise kernels have no group form: one launch per sample (= per replica in the backward)
-            dg = torch.empty_like(dc)
-            for r in range(dc.shape[0]):
-                if self.trainable(p + ".dw.weight") and not self._skip_wgrad:
-                    ops.dwconv1d_wgrad(g[r:r + 1], dc[r:r + 1], self.GR[p + ".dw.weight"][self._lo + r % self.active],
-                                       self.GR[p + ".dw.bias"][self._lo + r % self.active], beta=1.0)
-                ops.dwconv1d_dgrad(dc[r:r + 1], self.PR[p + ".dw.weight"][self._lo + r % self.active], out=dg[r:r + 1])
+        if self.R > 1:          # group forms of the depthwise kernels: sample r = replica lo + r
+            if self.trainable(p + ".dw.weight") and not self._skip_wgrad:
+                ops.dwconv1d_wgrad(g, dc, self._gw(p + ".dw.weight"), self._gw(p + ".dw.bias"), beta=1.0)
+            dg = ops.dwconv1d_dgrad(dc, self._w(p + ".dw.weight"))
             du = ops.glu_bwd(u, dg)
             dn = self._lin_bwd(du, n, p + ".pw1.weight", p + ".pw1.bias")
             return self._res_norm_bwd(h, p + ".norm.weight", p + ".norm.bias", mean, rstd, dn, dh)

@@ -719,18 +719,30 @@ def dwconv1d(x, w, bias, out=None):
 
 
 def dwconv1d_dgrad(dy, w, out=None, beta=0.0):
-    _cc(dy, "dwconv1d_dgrad.dy"); _cc(w, "dwconv1d_dgrad.w")
+    _cc(dy, "dwconv1d_dgrad.dy")
     B, T, C = dy.shape
     out = torch.empty_like(dy) if out is None else _cc(out, "dwconv1d_dgrad.out")
+    if _is_group(w):
+        _group_dims(dy, w.R, "dwconv1d_dgrad")
+        check(_L().dyn_dwconv1d_dgrad_g(dy.data_ptr(), w.data_ptr(), out.data_ptr(), B, T, C, w.shape[1], beta, w.R, w.stride, _stream()),
+              "dyn_dwconv1d_dgrad_g")
+        return out
+    _cc(w, "dwconv1d_dgrad.w")
     check(_L().dyn_dwconv1d_dgrad(dy.data_ptr(), w.data_ptr(), out.data_ptr(), B, T, C, w.shape[1], beta, _stream()),
           "dyn_dwconv1d_dgrad")
     return out
 
 
 def dwconv1d_wgrad(x, dy, dw, dbias, beta=1.0):
-    _cc(x, "dwconv1d_wgrad.x"); _cc(dy, "dwconv1d_wgrad.dy"); _cc(dw, "dwconv1d_wgrad.dw")
+    _cc(x, "dwconv1d_wgrad.x"); _cc(dy, "dwconv1d_wgrad.dy")
     B, T, C = x.shape
     ws = workspace(x.device)
+    if _is_group(dw):
+        _group_dims(x, dw.R, "dwconv1d_wgrad")
+        check(_L().dyn_dwconv1d_wgrad_g(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 0 if dbias is None else dbias.data_ptr(), beta, B, T, C,
+                                        dw.shape[1], dw.R, dw.stride, ws.data_ptr(), ws.numel(), _stream()), "dyn_dwconv1d_wgrad_g")
+        return
+    _cc(dw, "dwconv1d_wgrad.dw")
     check(_L().dyn_dwconv1d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _opt(dbias, "dbias"), beta, B, T, C,
                                   dw.shape[1], ws.data_ptr(), ws.numel(), _stream()), "dyn_dwconv1d_wgrad")
 
@@ -748,17 +760,12 @@ def convmod_fwd(u, w, bias, gamma, beta, layernorm, eps, save):
         g, c, nn = (torch.empty(B, T, C, device=dev, dtype=F32) for _ in range(3))
         rstd = torch.empty(B * T, device=dev, dtype=F32)
         mean = torch.empty(B * T, device=dev, dtype=F32) if layernorm else None
-    if _is_group(w):
-        R = w.R
-        _group_dims(u, R, "convmod")
-        for k in range(B):
-            r = k % R
-            sl = slice(k * T, (k + 1) * T)
-            check(_L().dyn_convmod_fwd(u[k].data_ptr(), w[r].data_ptr(), 0 if bias is None else bias[r].data_ptr(), gamma[r].data_ptr(),
-                                       0 if beta is None else beta[r].data_ptr(), s[k].data_ptr(), 0 if g is None else g[k].data_ptr(),
-                                       0 if c is None else c[k].data_ptr(), 0 if nn is None else nn[k].data_ptr(),
-                                       0 if mean is None else mean[sl].data_ptr(), 0 if rstd is None else rstd[sl].data_ptr(), 1, T, C, w.shape[1],
-                                       int(layernorm), eps, _stream()), "dyn_convmod_fwd")
+    if _is_group(w):        # lockstep group: one launch, sample k takes replica k % R's filters and norm weights
+        _group_dims(u, w.R, "convmod")
+        check(_L().dyn_convmod_fwd_g(u.data_ptr(), w.data_ptr(), 0 if bias is None else bias.data_ptr(), gamma.data_ptr(),
+                                     0 if beta is None else beta.data_ptr(), s.data_ptr(), _opt(g, "g"), _opt(c, "c"), _opt(nn, "nn"),
+                                     _opt(mean, "mean"), _opt(rstd, "rstd"), B, T, C, w.shape[1], int(layernorm), eps, w.R, w.stride, _stream()),
+              "dyn_convmod_fwd_g")
         return s, g, c, nn, mean, rstd
     _cc(w, "convmod.w")
     check(_L().dyn_convmod_fwd(u.data_ptr(), w.data_ptr(), _opt(bias, "bias"), gamma.data_ptr(), _opt(beta, "beta"), s.data_ptr(),

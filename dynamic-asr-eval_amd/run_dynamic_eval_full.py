@@ -84,8 +84,12 @@ def main(args):
     mine = ddist.shard_longest_first([d.get('frames', 1) for d in data], world)[rank]
 
     chains = int(args.__dict__.get('chains', 1))    # -kwargs chains=N: N recordings in flight per GPU (lib.dynamic_eval_many)
+    lockstep = int(args.__dict__.get('lockstep', 1))   # -kwargs lockstep=R: every chain is a lockstep group of R recordings (lib._dynamic_eval_group_gen)
     models = None
-    if chains > 1 and not args.awmc and len(mine) > 1:
+    if lockstep > 1 and not args.awmc and len(mine) > 1:
+        from .run_seq_eval import replicate
+        models = replicate(model, max(1, min(chains, (len(mine) + lockstep - 1) // lockstep)), group=lockstep)
+    elif chains > 1 and not args.awmc and len(mine) > 1:
         from .run_seq_eval import replicate
         models = replicate(model, min(chains, len(mine)))
 

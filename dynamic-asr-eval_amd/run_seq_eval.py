@@ -44,8 +44,21 @@ def outer_stitch(windows, overlap, num_classes, device):
     return ops.stitch_finalize(acc, cnt, end)
 
 
-def replicate(model, n):
-    """n - 1 more replicas of `model` (same config, same weights) for lib.dynamic_eval_many."""
+def replicate(model, n, group=1):
+    """n - 1 more replicas of `model` (same config, same weights) for lib.dynamic_eval_many; with `group` = R > 1, n LOCKSTEP-GROUP
+    models of R replicas each instead (`-kwargs lockstep=R`: R recordings advance through every window step in one batch per chain)."""
+    if group > 1:
+        if model.buffers:
+            raise ValueError("lockstep groups: batch_renorm models keep the one-recording-per-chain path")
+        out = []
+        for _ in range(max(1, n)):
+            m = SCConformerXL(dict(model.config), vocab_size=model.decoder.num_classes - 1, device=model.device, group=group)
+            m.load_state_dict(model.state_dict())
+            m.frozen = set(model.frozen)
+            m.fused_attention = model.fused_attention
+            m.eval()
+            out.append(m)
+        return out
     out = [model]
     for _ in range(max(0, n - 1)):
         m = SCConformerXL(dict(model.config), vocab_size=model.decoder.num_classes - 1, device=model.device)

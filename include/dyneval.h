@@ -186,6 +186,11 @@ int dyn_dwconv1d_dgrad(const float* dy, const float* w, float* dx, int64_t B, in
 int64_t dyn_dwconv1d_wgrad_workspace_bytes(int64_t B, int64_t T, int64_t C, int64_t KW);
 int dyn_dwconv1d_wgrad(const float* x, const float* dy, float* dw, float* dbias, float beta, int64_t B, int64_t T, int64_t C,
                        int64_t KW, void* workspace, int64_t workspace_bytes, void* stream);
+/* lockstep-group variants (see dyn_layernorm_fwd_g): sample b convolves with / accumulates into the filters of replica b % n_groups */
+int dyn_dwconv1d_dgrad_g(const float* dy, const float* w, float* dx, int64_t B, int64_t T, int64_t C, int64_t KW, float dx_beta,
+                         int64_t n_groups, int64_t param_stride, void* stream);
+int dyn_dwconv1d_wgrad_g(const float* x, const float* dy, float* dw, float* dbias, float beta, int64_t B, int64_t T, int64_t C, int64_t KW,
+                         int64_t n_groups, int64_t param_stride, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Fused conformer conv-module core (GLU -> depthwise k=9 -> RMSNorm | LayerNorm over channels -> SiLU), one pass:
  *   u [B, T, 2C] -> s [B, T, C];  optional outputs for the backward: g (GLU), c (conv), nn (norm output), mean, rstd [B*T].
@@ -193,6 +198,10 @@ int dyn_dwconv1d_wgrad(const float* x, const float* dy, float* dw, float* dbias,
 int dyn_convmod_fwd(const float* u, const float* w, const float* bias, const float* gamma, const float* beta, float* s,
                     float* g_out, float* c_out, float* nn_out, float* mean_out, float* rstd_out, int64_t B, int64_t T, int64_t C,
                     int64_t KWIDTH, int32_t layernorm, float eps, void* stream);
+/* lockstep-group variant (see dyn_layernorm_fwd_g): sample b of the batch takes w / bias / gamma / beta of replica b % n_groups */
+int dyn_convmod_fwd_g(const float* u, const float* w, const float* bias, const float* gamma, const float* beta, float* s, float* g_out,
+                      float* c_out, float* nn_out, float* mean_out, float* rstd_out, int64_t B, int64_t T, int64_t C, int64_t KWIDTH,
+                      int32_t layernorm, float eps, int64_t n_groups, int64_t param_stride, void* stream);
 
 /* dw_striding x8 subsampling (`subsampling: dw_striding`, `subsampling_conv_channels: 256`, `subsampling_act: silu`,
  * yaml:10-13), channels-last.  Output sizes: To = (T-1)/2+1, Fo = (F-1)/2+1 (3x3, stride 2, pad 1).

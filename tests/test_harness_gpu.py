@@ -50,6 +50,11 @@ def test_run_dynamic_eval_full(cuda, tmp_path, capsys):
         H.main(lib.apply_args(H.build_parser(), ["-d", "synthetic_small", "-s", sp] + noaug + [f"chains={chains}"]))
         res[chains] = pickle.load(open(sp.replace(".pkl", "_1.pkl"), "rb"))
     assert res[1]["model_output"] == res[2]["model_output"] and len(res[2]["elapsed_times"]) == 3
+    # -kwargs lockstep=3: the three recordings (14 s, 9 s, 11.5 s: different lengths) advance through every window step in ONE batch
+    sp = str(tmp_path / "lock.pkl")
+    H.main(lib.apply_args(H.build_parser(), ["-d", "synthetic_small", "-s", sp] + noaug + ["lockstep=3"]))
+    lock = pickle.load(open(sp.replace(".pkl", "_1.pkl"), "rb"))
+    assert lock["model_output"] == res[1]["model_output"] and lock["wer"] == res[1]["wer"]
     # -awmc goes through the same harness (reference run_dynamic_eval_full.py:67-68)
     args = lib.apply_args(H.build_parser(), ["-d", "synthetic_small", "-awmc"] + _argv(ckpt, []))
     assert H.main(args) >= 0
