@@ -68,9 +68,11 @@ def parse():
     ap.add_argument("--final_batch", type=int, default=4, help="windows per forward in the final pass (they are independent)")
     ap.add_argument("--pcie", type=int, default=0, help="1: recordings start in HOST memory and results come back as numpy (the "
                     "PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
-    ap.add_argument("--chains", type=int, default=3, help="independent recordings in flight per GPU (own stream + model replica)")
-    ap.add_argument("--lockstep", type=int, default=1, help="R > 1: every chain is a LOCKSTEP GROUP of R recordings advancing through the same window "
-                    "step in one batch (SCConformerXL(group=R): one launch per layer for all R, each recording with its own weights); chains x R recordings in flight")
+    ap.add_argument("--chains", type=int, default=2, help="independent chains in flight per GPU (own stream + model object each)")
+    ap.add_argument("--lockstep", type=int, default=4, help="R > 1: every chain is a LOCKSTEP GROUP of R recordings advancing through the same window "
+                    "step in one batch (SCConformerXL(group=R): one launch per layer for all R, each recording with its own weights); chains x R "
+                    "recordings in flight.  Default 2 chains x 4 (r04, driver form on one box: 805 audio-s/s against 791 for 3 chains x 1, "
+                    "profiles/r04_ab_lockstep_driver_form.log); --lockstep 1 --chains 3 is the r03 configuration")
     return ap.parse_args()
 
 
