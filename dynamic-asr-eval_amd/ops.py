@@ -322,7 +322,8 @@ def gemm_profile_stop():
     prof, GEMM_PROFILE = GEMM_PROFILE, None
     if prof is None:
         return None
-    out = {"calls": prof["calls"], "flops": prof["flops"], "bytes": prof["bytes"], "attn_flops": prof.get("attn_flops", 0.0)}
+    out = {"calls": prof["calls"], "flops": prof["flops"], "bytes": prof["bytes"], "attn_flops": prof.get("attn_flops", 0.0),
+           "sampled_steps": (prof["windows"] + prof["window_every"] - 1) // prof["window_every"] if prof.get("window_every") else prof.get("windows", 0)}
     for key, name in (("samples", "shared"), ("samples_excl", "exclusive")):
         out[name] = {"sampled": len(prof[key]), "flops": sum(s[0] for s in prof[key]),
                      "ms": sum(s[1].elapsed_time(s[2]) for s in prof[key])}
