@@ -197,9 +197,9 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int roff,
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-template <bool KMAJOR, int R>
+template <bool KMAJOR, int R, int NW = 4>
 struct GldsStager {
-    static constexpr int NI = R * BK / 1024;   // 1-KiB pieces per wave per tile (4 waves): R=128 -> 4, R=64 -> 2
+    static constexpr int NI = R * BK / (256 * NW);   // 1-KiB pieces per wave per tile: 4 waves: R=128 -> 4, R=64 -> 2; 8 waves: R=256 -> 4, R=128 -> 2
     const float* ptr[NI];
     int64_t step;
     __device__ __forceinline__ void init(const float* base, int64_t ld, int64_t row0, int64_t rows, int64_t k0, int wave, int lane) {
@@ -244,11 +244,15 @@ __device__ __forceinline__ void read_frag_glds(const float* __restrict__ s, int 
 
 // One output tile (or one K slice of it) by one 256-thread workgroup.  `bid` = position of this workgroup among the launch's work
 // items (the single-GEMM kernel passes blockIdx.x; the grouped kernel passes the index inside the group, already remapped).
-template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, bool GROUPED>
+// NW = waves per workgroup: 4 (2 x 2 over the tile) or 8 (4 x 2: the 256x128 tile, direct-to-LDS staging only — a wave's share of the tile is
+// 64x64 as in the 128x128 tile, but the workgroup moves 25 % fewer operand bytes per MFMA through the L2 -> LDS path).
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, bool GROUPED, int NW = 4>
 __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, float* smem) {
     constexpr bool AK = !TA;  // A has K contiguous in HBM
     constexpr bool BKM = TB;  // B has K contiguous in HBM
-    constexpr int WTM = BM / 64, WTN = BN / 64;  // 32x32 tiles per wave along M / N
+    constexpr int WM = NW / 2;                          // waves along M (2 along N)
+    constexpr int WTM = BM / (32 * WM), WTN = BN / 64;  // 32x32 tiles per wave along M / N
+    static_assert(NW == 4 || (NW == 8 && GLDS), "the 8-wave tile exists for direct-to-LDS staging only");
     static_assert(!GLDS || (VEC && BK == 32), "direct-to-LDS staging needs 16-B aligned operands and BK = 32");
     constexpr int SA = GLDS ? BM * BK : BM * LDK, SB = GLDS ? BN * BK : BN * LDK;  // floats per stage
 
@@ -314,8 +318,8 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
             load_tile<BKM, BN, VEC>(B, p.ldb, n0, p.N, k0, kend, rb);
         }
     };
-    GldsStager<AK, BM> stA;
-    GldsStager<BKM, BN> stB;
+    GldsStager<AK, BM, NW> stA;
+    GldsStager<BKM, BN, NW> stB;
     if (GLDS) {
         stA.init(A, p.lda, m0, p.M, kbeg, wave, lane);
         stB.init(B, p.ldb, n0, p.N, kbeg, wave, lane);
@@ -343,8 +347,8 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
     auto read_chunk = [&](const float* sa, const float* sb, int c, int slot) {
 #pragma unroll
         for (int a = 0; a < WTM; ++a) {
-            if (GLDS) read_frag_glds<AK, BM>(sa, wm * (BM / 2) + a * 32, i, h, c, fa[slot][a]);
-            else read_frag<AK, BM>(sa, wm * (BM / 2) + a * 32, i, h, c, fa[slot][a]);
+            if (GLDS) read_frag_glds<AK, BM>(sa, wm * (BM / WM) + a * 32, i, h, c, fa[slot][a]);
+            else read_frag<AK, BM>(sa, wm * (BM / WM) + a * 32, i, h, c, fa[slot][a]);
         }
 #pragma unroll
         for (int b = 0; b < WTN; ++b) {
@@ -410,7 +414,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #pragma unroll
         for (int a = 0; a < WTM; ++a) {
             const float tot = csum[a] + __shfl_xor(csum[a], 32);
-            const int64_t m = m0 + wm * (BM / 2) + a * 32 + i;
+            const int64_t m = m0 + wm * (BM / WM) + a * 32 + i;
             if (h == 0 && m < p.M) p.colsum[m] = (p.colsum_beta != 0.f ? p.colsum_beta * p.colsum[m] : 0.f) + tot;
         }
     }
@@ -423,7 +427,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
             for (int a = 0; a < WTM; ++a)
 #pragma unroll
                 for (int b = 0; b < WTN; ++b) {
-                    float* wp = W + (wm * (BM / 2) + a * 32 + 4 * h) * BN + wn * (BN / 2) + b * 32 + i;
+                    float* wp = W + (wm * (BM / WM) + a * 32 + 4 * h) * BN + wn * (BN / 2) + b * 32 + i;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) wp[((e & 3) + 8 * (e >> 2)) * BN] = acc[a][b][e];
                 }
@@ -436,7 +440,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
                     const int64_t col = n0 + wn * (BN / 2) + b * 32 + i;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const int64_t row = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const int64_t row = m0 + wm * (BM / WM) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                         if (row < p.M && col < p.N) W[row * p.N + col] = acc[a][b][e];
                     }
                 }
@@ -455,7 +459,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
         for (int a = 0; a < WTM; ++a)
 #pragma unroll
             for (int b = 0; b < WTN; ++b) {
-                float* wp = W + (wm * (BM / 2) + a * 32 + 4 * h) * BN + wn * (BN / 2) + b * 32 + i;
+                float* wp = W + (wm * (BM / WM) + a * 32 + 4 * h) * BN + wn * (BN / 2) + b * 32 + i;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) wp[((e & 3) + 8 * (e >> 2)) * BN] = acc[a][b][e];
             }
@@ -470,7 +474,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
         for (int a = 0; a < WTM; ++a)
 #pragma unroll
             for (int b = 0; b < WTN; ++b) {
-                const float* rp = W0 + (wm * (BM / 2) + a * 32 + 4 * h) * BN + wn * (BN / 2) + b * 32 + i;
+                const float* rp = W0 + (wm * (BM / WM) + a * 32 + 4 * h) * BN + wn * (BN / 2) + b * 32 + i;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float* q = rp + ((e & 3) + 8 * (e >> 2)) * BN;
@@ -489,7 +493,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
             for (int b = 0; b < WTN; ++b) {
                 const int64_t col = n0 + wn * (BN / 2) + b * 32 + i;
                 const float bv = p.bias ? p.bias[z1 * p.bs1 + z2 * p.bs2 + col] : 0.f;
-                float* cp = C + (m0 + wm * (BM / 2) + a * 32 + 4 * h) * p.ldc + col;
+                float* cp = C + (m0 + wm * (BM / WM) + a * 32 + 4 * h) * p.ldc + col;
                 if (p.epi != 0) {             // activation fused into the store (host guarantees: no split / tail, aux set)
                     const int64_t ad = p.aux - p.C;
 #pragma unroll
@@ -520,7 +524,7 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
                 const float bv = (p.bias && col < p.N) ? p.bias[z1 * p.bs1 + z2 * p.bs2 + col] : 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int64_t row = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int64_t row = m0 + wm * (BM / WM) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (row < p.M && col < p.N) {
                         float v = epi_value(p.alpha, acc[a][b][e], p.beta, C + row * p.ldc + col + p.cin_delta, bv);
                         if (p.epi == 1) { if (p.aux) C[row * p.ldc + col + (p.aux - p.C)] = v; v = silu_f(v); }
@@ -538,11 +542,11 @@ __device__ __forceinline__ void gemm_tile(const KParams& p, const int64_t bid, f
 #ifndef DYN_GEMM_WAVES_PER_EU
 #define DYN_GEMM_WAVES_PER_EU 2
 #endif
-template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DYN_GEMM_WAVES_PER_EU, 8))) void gemm_f32_kernel(const KParams p) {
+template <bool TA, bool TB, int BM, int BN, bool VEC, bool GLDS, int NW = 4>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(DYN_GEMM_WAVES_PER_EU, 8))) void gemm_f32_kernel(const KParams p) {
     constexpr int SA = GLDS ? BM * BK : BM * LDK, SB = GLDS ? BN * BK : BN * LDK;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
-    gemm_tile<TA, TB, BM, BN, VEC, GLDS, false>(p, (int64_t)blockIdx.x, smem);
+    __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];       // 64 KB at 128x128, 96 KB at 256x128 (160 KB of LDS per CU on gfx950)
+    gemm_tile<TA, TB, BM, BN, VEC, GLDS, false, NW>(p, (int64_t)blockIdx.x, smem);
 }
 
 // Grouped launch: ONE grid over the tiles of up to kMaxGroups independent GEMMs that share (TA, TB) and the tile shape (the
@@ -644,8 +648,19 @@ struct Plan {
 // N, K in {128 ... 4096}).  A "round" is one workgroup per slot (slots = resident workgroups per CU x 256 CUs); a partial
 // last round is the classic wave-quantisation loss, so when no global split-K is used its items are K-sliced tail_f ways
 // (tail_f = slots / remainder) and run as one short, full round.
-double tile_eff(int bm, int bn) { return (bm == 128 && bn == 128) ? 0.80 : (bm == 64 && bn == 64) ? 0.62 : 0.72; }
-int tile_occ(int bm, int bn) { return (bm == 64 && bn == 64) ? 4 : (bm == 128 && bn == 128) ? 2 : 3; }  // resident workgroups per CU (LDS-bound)
+double tile_eff(int bm, int bn) { return bm == 256 ? 0.84 : (bm == 128 && bn == 128) ? 0.80 : (bm == 64 && bn == 64) ? 0.62 : 0.72; }
+int tile_occ(int bm, int bn) { return bm == 256 ? 1 : (bm == 64 && bn == 64) ? 4 : (bm == 128 && bn == 128) ? 2 : 3; }  // resident workgroups per CU (LDS-bound)
+
+// direct-to-LDS staging: whole K tiles only (no zero fill), 16-B aligned operands, and an operand whose rows are the contiguous axis
+// must have a row count that is a multiple of 4 (edge clamping works on 16-B groups).  The 256x128 tile has no other staging.
+bool glds_eligible(const dyn_gemm_desc* d) {
+    auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+    const bool vec = al16(d->A) && al16(d->B) && (d->lda % 4 == 0) && (d->ldb % 4 == 0) && (d->sa1 % 4 == 0) && (d->sa2 % 4 == 0) &&
+                     (d->sb1 % 4 == 0) && (d->sb2 % 4 == 0);
+    static const bool allow_glds = [] { const char* e = getenv("DYN_GEMM_GLDS"); return !e || atoi(e) != 0; }();
+    const bool ta = d->trans_a != 0, tb = d->trans_b != 0;
+    return allow_glds && vec && d->K % BK == 0 && d->K > 0 && (!ta || d->M % 4 == 0) && (tb || d->N % 4 == 0) && (!ta || d->M >= 4) && (tb || d->N >= 4);
+}
 
 // One configuration: tile (bm, bn), global split-K s, tail slicing f_req (-1 = slots / remainder, 1 = off, n = forced).
 bool eval_config(const dyn_gemm_desc* d, int bm, int bn, int s, int f_req, Plan* out, double* cost) {
@@ -689,7 +704,8 @@ Plan make_plan(const dyn_gemm_desc* d) {
     Plan best;
     double cost;
     if (d->tile_m > 0 && d->tile_n > 0) {  // caller-forced configuration (autotuner, tests)
-        eval_config(d, d->tile_m >= 128 ? 128 : 64, d->tile_n >= 128 ? 128 : 64, d->split_k > 0 ? d->split_k : 1,
+        const bool big = d->tile_m >= 256 && d->tile_n >= 128 && glds_eligible(d);       // 256x128: direct-to-LDS operands only
+        eval_config(d, big ? 256 : d->tile_m >= 128 ? 128 : 64, d->tile_n >= 128 ? 128 : 64, d->split_k > 0 ? d->split_k : 1,
                     d->tail_slices > 0 ? d->tail_slices : 1, &best, &cost);
         return best;
     }
@@ -698,7 +714,7 @@ Plan make_plan(const dyn_gemm_desc* d) {
         for (int i = 0; i < kNumTuned; ++i) {
             const Tuned& t = kTuned[i];
             if (t.ta == (d->trans_a != 0) && t.tb == (d->trans_b != 0) && t.M == d->M && t.N == d->N && t.K == d->K && t.batch == batch) {
-                eval_config(d, t.bm, t.bn, t.split, t.tail, &best, &cost);
+                eval_config(d, (t.bm == 256 && !glds_eligible(d)) ? 128 : t.bm, t.bn, t.split, t.tail, &best, &cost);
                 return best;
             }
         }
@@ -736,7 +752,8 @@ void launch_vec(const KParams& kp, bool vec, dim3 grid, hipStream_t st) {
 
 template <bool TA, bool TB>
 void launch_tile(const KParams& kp, const Plan& pl, bool vec, dim3 grid, hipStream_t st) {
-    if (pl.bm == 128 && pl.bn == 128) launch_vec<TA, TB, 128, 128>(kp, vec, grid, st);
+    if (pl.bm == 256) hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 256, 128, true, true, 8>), grid, dim3(512), 0, st, kp);   // planned only when glds_eligible()
+    else if (pl.bm == 128 && pl.bn == 128) launch_vec<TA, TB, 128, 128>(kp, vec, grid, st);
     else if (pl.bm == 128 && pl.bn == 64) launch_vec<TA, TB, 128, 64>(kp, vec, grid, st);
     else if (pl.bm == 64 && pl.bn == 128) launch_vec<TA, TB, 64, 128>(kp, vec, grid, st);
     else launch_vec<TA, TB, 64, 64>(kp, vec, grid, st);

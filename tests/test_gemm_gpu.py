@@ -72,7 +72,7 @@ def test_gemm_two_level_batch(cuda):
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(100, 72, 64), (67, 129, 32), (1992, 200, 128), (260, 4, 96), (4, 260, 32)])
-@pytest.mark.parametrize("tile", [(128, 128, 1), (64, 64, 1), (128, 64, 3), (64, 128, 1)])
+@pytest.mark.parametrize("tile", [(128, 128, 1), (64, 64, 1), (128, 64, 3), (64, 128, 1), (256, 128, 1), (256, 128, 2)])
 def test_gemm_direct_to_lds_edges(cuda, ta, tb, M, N, K, tile):
     """K % 32 == 0 and 16-B aligned operands select the direct-to-LDS kernel (when the row-contiguous operands have a row
     count that is a multiple of 4; otherwise the register-staged kernel): ragged M/N edges are clamped loads there, so check
@@ -106,6 +106,31 @@ def test_gemm_direct_to_lds_matches_register_staged_bitwise(cuda):
     buf_b = torch.empty(N * K + 1, device=cuda); buf_b[1:].copy_(b.flatten())
     ops.gemm(buf_a, buf_b, c2, trans_b=True, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_off=1, b_off=1, force=(128, 128, 1))
     assert torch.equal(c1, c2)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_256x128_tile_is_bit_identical_to_128x128(cuda, ta, tb):
+    """r04: the 8-wave 256x128 tile (direct-to-LDS staging only; 96 KB of LDS) gives every output element the same fmaf chain over k as the
+    4-wave tiles: bit-identical results, batched over two levels with a bias, a residual and alpha / beta, ragged edges, tail slicing."""
+    from dynamic_asr_eval_amd import ops
+    g = torch.Generator().manual_seed(77 + 2 * ta + tb)
+    for (M, N, K, nb1, nb2) in ((2048, 768, 768, 2, 3), (1992, 3072, 768, 1, 2), (700, 260, 96, 1, 1)):
+        batch = nb1 * nb2
+        a = torch.randn((batch, K, M) if ta else (batch, M, K), generator=g).to(cuda)
+        b = torch.randn((nb2, N, K) if tb else (nb2, K, N), generator=g).to(cuda)      # the second batch level steps through the weights
+        bias = torch.randn(nb2, N, generator=g).to(cuda)
+        res = torch.randn(batch, M, N, generator=g).to(cuda)
+        outs = []
+        for tile in ((128, 128, 1), (256, 128, 1), (256, 128, 3)):
+            c = torch.empty(batch, M, N, device=cuda)
+            ops.gemm(a, b, c, trans_a=ta, trans_b=tb, M=M, N=N, K=K, lda=a.shape[2], ldb=b.shape[2], ldc=N, nb1=nb1, nb2=nb2,
+                     sa=(nb2 * a.shape[1] * a.shape[2], a.shape[1] * a.shape[2]), sb=(0, b.shape[1] * b.shape[2]), sc=(nb2 * M * N, M * N),
+                     bias=bias, sbias=(0, N), alpha=0.5, beta=1.0, c_in=res, force=tile)
+            outs.append(c)
+        assert torch.equal(outs[0], outs[1]), (M, N, K, "256x128 differs from 128x128")
+        assert torch.equal(outs[0], outs[2]) or (outs[0] - outs[2]).abs().max().item() < 1e-4 * K ** 0.5, (M, N, K, "tail-sliced 256x128")
+        ref = 0.5 * torch.stack([_ref(a[i], b[i % nb2], ta, tb) for i in range(batch)]) + res.double().cpu() + bias.double().cpu()[torch.arange(batch) % nb2][:, None, :]
+        assert (outs[1].double().cpu() - ref).abs().max().item() < 2e-5 * K ** 0.5 * 4
 
 
 def test_grouped_weight_gradients_match_single_launches_and_sum_the_bias(cuda):
