@@ -461,8 +461,6 @@ def lockstep_supported(args, model, specs, beam_search_fn=None, optimizer_state=
         return False
     if not a.get('skip_zero_grad_samples', True):
         return False
-    if len({int(sp.shape[-1]) for sp in specs}) > 1 and (a.get('epochs', 1) != 1 or (a.get('shuffle', False) and not a.get('online', False))):
-        return False        # one optimiser step counter per group: recordings of different lengths stay in step only over ONE in-order epoch
     return len({int(sp.shape[-2]) for sp in specs}) == 1
 
 
@@ -486,7 +484,8 @@ def _dynamic_eval_group_gen(args, model, specs, seq_len, overlap, tokenizer, use
     recording's loss and gradient scaled as if it were alone: reduction 'sum', 1 / (N * B) with B = 1), one backward on the n augmented
     samples — and ONE optimiser launch over the [n, n_flat] buffers of the recordings still adapting.  Recordings of different lengths share
     the window grid (same seq_len / overlap): they are ordered longest first, the full windows run on a shrinking prefix of the replicas,
-    a recording's short last window runs on its own replica, and a finished recording's replica is no longer stepped.  Recordings stay
+    a recording's short last window runs on its own replica, a finished recording's replica is no longer stepped, and every recording keeps
+    its own optimiser step count (over several epochs, or under shuffle, recordings of different lengths get out of step).  Recordings stay
     independent (own weights, own optimiser state, own stitch buffers): per recording the results are those of `dynamic_eval` up to the GEMM
     planner's choice of tile for the larger launches.  Generator with the same yield points as _dynamic_eval_gen; returns the list of
     per-recording results (in `specs` order) in StopIteration.value."""
@@ -550,6 +549,7 @@ def _dynamic_eval_group_gen(args, model, specs, seq_len, overlap, tokenizer, use
     model.use_graphs = bool(args.__dict__.get('use_graphs', True))
     model.eval()
     all_keys = sorted(set().union(*[set(d.keys()) for d in data]))
+    ksteps = [0] * Rn            # every recording keeps its own optimiser step count (recordings of different lengths get out of step after one epoch)
     pinned = None
     tgt_ring, tgt_turn = None, 0
     results = [None] * Rn
@@ -634,7 +634,19 @@ def _dynamic_eval_group_gen(args, model, specs, seq_len, overlap, tokenizer, use
                     if online:
                         for q in range(lo, hi):
                             stitch_window(q, i, post[n + q - lo].detach(), u_lens[q])
-                optimizer.step(limit=(members[-1] + 1) * n_flat)       # the recordings that had a window at this position (a prefix)
+                # one optimiser launch per run of recordings with the same step count (one launch when they are in step), over the recordings that
+                # had a window at this position; a finished recording's replica is left alone
+                runs, start, prev = [], members[0], members[0]
+                for q in members[1:]:
+                    if q == prev + 1 and ksteps[q] == ksteps[start]:
+                        prev = q
+                        continue
+                    runs.append((start * n_flat, (prev + 1) * n_flat, ksteps[start]))
+                    start = prev = q
+                runs.append((start * n_flat, (prev + 1) * n_flat, ksteps[start]))
+                optimizer.step_ranges(runs)
+                for q in members:
+                    ksteps[q] += 1
                 if sampled:
                     ops.gemm_profile_end_step(device, sampled)
         if not online:

@@ -88,6 +88,24 @@ class MADGRAD(_FlatOptimizer):
             ops.madgrad_step(p, g, s, nu, x0, d["lr"], d["momentum"], d["weight_decay"], d["eps"], self.k)
         self.k += 1
 
+    def step_ranges(self, ranges):
+        d = self.defaults
+        _step_ranges(self, ranges, 3, lambda p, g, b, k: ops.madgrad_step(p, g, b[0], b[1], b[2], d["lr"], d["momentum"], d["weight_decay"], d["eps"], k))
+
+
+def _step_ranges(opt, ranges, n_bufs, launch):
+    """Shared by MADGRAD / Adam: one launch per (lo, hi, k) run of the flat buffers — the replicas of a lockstep group whose recordings have
+    taken the same number of steps form one run (recordings of different lengths over several epochs, or under shuffle, get out of step: each
+    keeps its OWN step count, as each would have alone)."""
+    pairs = opt._iter_pairs()
+    if opt._pairs is None or len(pairs) != 1:
+        raise ops.DynError("step_ranges: only for a model's flat parameter buffer")
+    opt._alloc_state(pairs, n_bufs)
+    (p, g), bufs = pairs[0], opt.state[0]
+    for lo, hi, k in ranges:
+        launch(p[lo:hi], g[lo:hi], [b[lo:hi] for b in bufs], int(k))
+    opt.k = max([opt.k] + [int(k) + 1 for _, _, k in ranges])
+
 
 class Adam(_FlatOptimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
@@ -102,3 +120,7 @@ class Adam(_FlatOptimizer):
                 p, g, m, v = p[:limit], g[:limit], m[:limit], v[:limit]
             ops.adam_step(p, g, m, v, d["lr"], d["betas"][0], d["betas"][1], d["eps"], d["weight_decay"], self.k)
         self.k += 1
+
+    def step_ranges(self, ranges):
+        d = self.defaults
+        _step_ranges(self, ranges, 2, lambda p, g, b, k: ops.adam_step(p, g, b[0], b[1], d["lr"], d["betas"][0], d["betas"][1], d["eps"], d["weight_decay"], k))

@@ -87,8 +87,12 @@ def main(args):
     if rank == 0:
         print([el.get('frames', 0) / 6000.0 for el in data])
     chains = int(args.__dict__.get('chains', 1))
-    eval_fn = dynamic_eval if not args.awmc else AWMC
-    models = replicate(model, chains) if (chains > 1 and not args.awmc) else [model]
+    lockstep = int(args.__dict__.get('lockstep', 1))     # -kwargs lockstep=R: R outer windows per chain advance in one batch (they are independent
+    eval_fn = dynamic_eval if not args.awmc else AWMC    # recordings as far as eval_fn goes: weights restored, fresh optimiser, lib.py:494,636-637)
+    if lockstep > 1 and not args.awmc:
+        models = replicate(model, max(1, chains), group=lockstep)
+    else:
+        models = replicate(model, chains) if (chains > 1 and not args.awmc) else [model]
     mine = ddist.shard_longest_first([d.get('frames', 1) for d in data], world)[rank]
 
     wers = []
@@ -108,7 +112,7 @@ def main(args):
             training_data, training_keys = prepare_chunks(audio_dev, seq_len, ov)
             keys = list(training_data.keys())
             chunks = [training_data[i] for i in keys]
-            if len(models) > 1:
+            if len(models) > 1 or getattr(models[0], "R", 1) > 1:
                 outs = lib.dynamic_eval_many(args, models, chunks, args.seq_len, args.overlap, tokenizer, use_tqdm=False,
                                              return_device=True)
             else:

@@ -102,6 +102,10 @@ def test_run_seq_eval_outer_windows(cuda, tmp_path, capsys):
         outs[chains] = pickle.load(open(path.replace(".pkl", "_1.pkl"), "rb"))
         assert avg >= 0
     assert outs[1]["model_output"] == outs[2]["model_output"] and len(outs[1]["model_output"]) == 5
+    # the outer windows of a recording as a lockstep group (-kwargs lockstep=2): same transcripts
+    path = str(tmp_path / "outer_lock.pkl")
+    S.main(lib.apply_args(S.build_parser(), ["-d", "synthetic_small", "-s", path, "-nsti_s", "768", "-nsti_o", "256"] + common + ["lockstep=2"]))
+    assert pickle.load(open(path.replace(".pkl", "_1.pkl"), "rb"))["model_output"] == outs[1]["model_output"]
     assert set(outs[1]) >= {"wer", "words", "ins_rate", "del_rate", "sub_rate", "model_output", "gold", "args_dict", "repeat"}
     out = capsys.readouterr().out
     assert "WER: " in out and "Average WER: " in out
