@@ -209,7 +209,7 @@ class SCConformerXL:
         self._ctx = None
         self._skip_wgrad = False
         self.use_graphs = False     # hipGraph replay of the forward / backward launch sequences (see forward())
-        self._graphs = {"fwd": {}, "bwd": {}, "seen": {}, "pool": None}
+        self._graphs = {"fwd": {}, "bwd": {}, "seen": {}, "pool": {}}
         self._ctx_static = False
         self._ctx_key = None
         self.fused_convmod = True   # GLU + dwconv + norm + SiLU in one kernel (csrc/convmod.hip)
@@ -449,6 +449,19 @@ class SCConformerXL:
         with ops.use_workspace(self._scratch()):
             return self._forward(audio_signal)
 
+    def _graph_pool(self):
+        """One private memory pool per replica range.  Graphs that share a pool may hand each other's freed capture-time memory around, which is
+        only safe when they replay in capture order.  A lockstep group whose recordings have different lengths runs SEVERAL shape classes per window
+        step as forward(class 1), forward(class 2), backward(class 1), backward(class 2): with one pool, a backward graph of class 1 captured in an
+        earlier call can own, as a temporary, the very memory a forward graph of class 2 captured later keeps its saved activations in (seen: two
+        epochs after one-epoch runs, 0.4 off on the shortest recording).  Classes of one step have disjoint replica ranges, so a pool per range keeps
+        their graphs apart; within a range forward and backward alternate strictly."""
+        pools = self._graphs["pool"]
+        key = (self._lo, self._n)
+        if key not in pools:
+            pools[key] = torch.cuda.graph_pool_handle()
+        return pools[key]
+
     def _forward(self, audio_signal):
         """Eager launch sequence, or — with `use_graphs` — a hipGraph replay of it.  A (shape, grad-mode) pair is captured
         the second time it is seen (one-off shapes such as the short last window stay eager); the captured graph owns its
@@ -470,15 +483,14 @@ class SCConformerXL:
             if G["seen"][key] < 2:
                 self._ctx_static = False
                 return self._forward_eager(x)
-            if G["pool"] is None:
-                G["pool"] = torch.cuda.graph_pool_handle()
+            self._graph_pool()
             # capture_error_mode="thread_local": other threads of the process (the RCCL watchdog of a multi-rank run) may
             # touch the HIP runtime while this thread captures; only this thread's calls are part of the capture
             static_in = x.clone()
             graph = torch.cuda.CUDAGraph()
             prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None      # no event records inside a capture
             try:
-                with _no_gc(), torch.cuda.graph(graph, pool=G["pool"], capture_error_mode="thread_local"), _capture_guard():
+                with _no_gc(), torch.cuda.graph(graph, pool=self._graph_pool(), capture_error_mode="thread_local"), _capture_guard():
                     out = self._forward_eager(static_in)
             finally:
                 ops.GEMM_PROFILE = prof
@@ -708,7 +720,7 @@ class SCConformerXL:
             graph = torch.cuda.CUDAGraph()
             prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
             try:
-                with _no_gc(), torch.cuda.graph(graph, pool=G["pool"], capture_error_mode="thread_local"), _capture_guard():
+                with _no_gc(), torch.cuda.graph(graph, pool=self._graph_pool(), capture_error_mode="thread_local"), _capture_guard():
                     self._backward(static_g, n_active, False)
             finally:
                 ops.GEMM_PROFILE = prof
