@@ -249,3 +249,46 @@ def test_bench_recording_is_inside_the_literal_bar(cuda):
         print(f"bench recording, {name}: max |dlogp| = {d:.2e}")
         assert d < 1e-3, f"{name}: {d:.3e}"
         assert np.array_equal(got.argmax(-1), want.argmax(-1)), name
+
+
+def test_lockstep_group_at_full_size_matches_the_oracle(cuda):
+    """bench.py's default since r04 — recordings in lockstep groups — against the CPU oracle AT THE CONFIG-2 SHAPE: a group of two recordings
+    (one full 16384-frame window + a short tail each, different lengths, per-recording masks) through lib.dynamic_eval_lockstep, offline and
+    online, each recording against oracle/dynamic_eval_ref.py run on it alone: stitched log-probs within 1e-3 (two carried MADGRAD steps on
+    the bias-0 weights: the benign-lattice regime, see the drift tests), argmax ids identical up to oracle near-ties.  This is where the
+    batched-over-weights GEMM plans of the tuned table, the group forms of the norm / conv-module / depthwise kernels and the per-range
+    graph pools meet the oracle at 6 x 768 / V+1 = 4096."""
+    import argparse
+    from oracle import dynamic_eval_ref as R
+    from oracle.conformer_ref import SCConformerXLRef
+    from oracle.madgrad_ref import MADGRAD as MADGRAD_REF
+    from dynamic_asr_eval_amd import lib
+    from dynamic_asr_eval_amd.datasets import synthetic_spec
+    from dynamic_asr_eval_amd.model import SCConformerXL
+    from dynamic_asr_eval_amd.tokenizer import SyntheticTokenizer
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = SCConformerXLRef(vocab_size=VOCAB, seed=0, blank_bias=0.0)
+    grp = SCConformerXL(vocab_size=VOCAB, device=cuda, group=2)
+    grp.load_state_dict(ref.state_dict())
+    OVL = 14336
+    tok = SyntheticTokenizer(VOCAB)
+    specs = [synthetic_spec(SEQ + 1200, seed=501), synthetic_spec(SEQ + 1800, seed=502)]
+    g = torch.Generator().manual_seed(12)
+    masks = [{k: (R.draw_masks(6, 34, 80, g), ([], [])) for k in (0, SEQ - OVL)} for _ in specs]
+
+    def args(online):
+        ns = argparse.Namespace(config={'model': {'subsampling_factor': 8}, 'audio_chunking': {'size': SEQ, 'overlap': 0}, 'training': {}})
+        ns.__dict__.update(dict(optim_lr=9e-5, epochs=1, shuffle=False, online=online, quiet=True, spec_augment_fixed_masks=masks))
+        return ns
+    want = [R.dynamic_eval_ref(ref, sp, SEQ, OVL, tok, MADGRAD_REF, {'lr': 9e-5}, {}, fixed_masks=m, also_online=True) for sp, m in zip(specs, masks)]
+    before = grp.flat_params.clone()
+    for online in (False, True):
+        got = lib.dynamic_eval_lockstep(args(online), grp, specs, SEQ, OVL, tok, use_tqdm=False)
+        assert torch.equal(grp.flat_params, before)
+        for r in range(2):
+            w = want[r][1 if online else 0]
+            assert got[r].shape == w.shape, (online, r, got[r].shape, w.shape)
+            d = float(np.abs(got[r] - w).max())
+            print(f"lockstep full size, {'online' if online else 'offline'}, recording {r}: max |dlogp| = {d:.2e}")
+            assert d < 1e-3, (online, r, d)
+            _argmax_check(torch.from_numpy(got[r]), torch.from_numpy(w), f"lockstep recording {r}")
