@@ -254,8 +254,10 @@ def test_bench_recording_is_inside_the_literal_bar(cuda):
 def test_lockstep_group_at_full_size_matches_the_oracle(cuda):
     """bench.py's default since r04 — recordings in lockstep groups — against the CPU oracle AT THE CONFIG-2 SHAPE: a group of two recordings
     (one full 16384-frame window + a short tail each, different lengths, per-recording masks) through lib.dynamic_eval_lockstep, offline and
-    online, each recording against oracle/dynamic_eval_ref.py run on it alone: stitched log-probs within 1e-3 (two carried MADGRAD steps on
-    the bias-0 weights: the benign-lattice regime, see the drift tests), argmax ids identical up to oracle near-ties.  This is where the
+    online, each recording against oracle/dynamic_eval_ref.py run on it alone AND against the one-recording HIP path on the same weights:
+    two carried MADGRAD steps put either HIP path 0.5e-3 - 1.2e-3 from the fp32 oracle (the drift tests say why); the group must be inside
+    max(1e-3, 1.5 x the single path's own distance) and 3e-3 of the oracle, within 1e-3 of the single path, argmax ids identical up to
+    oracle near-ties.  This is where the
     batched-over-weights GEMM plans of the tuned table, the group forms of the norm / conv-module / depthwise kernels and the per-range
     graph pools meet the oracle at 6 x 768 / V+1 = 4096."""
     import argparse
@@ -281,14 +283,20 @@ def test_lockstep_group_at_full_size_matches_the_oracle(cuda):
         ns.__dict__.update(dict(optim_lr=9e-5, epochs=1, shuffle=False, online=online, quiet=True, spec_augment_fixed_masks=masks))
         return ns
     want = [R.dynamic_eval_ref(ref, sp, SEQ, OVL, tok, MADGRAD_REF, {'lr': 9e-5}, {}, fixed_masks=m, also_online=True) for sp, m in zip(specs, masks)]
+    single = SCConformerXL(vocab_size=VOCAB, device=cuda)
+    single.load_state_dict(ref.state_dict())
     before = grp.flat_params.clone()
     for online in (False, True):
         got = lib.dynamic_eval_lockstep(args(online), grp, specs, SEQ, OVL, tok, use_tqdm=False)
         assert torch.equal(grp.flat_params, before)
         for r in range(2):
+            a1 = args(online)
+            a1.spec_augment_fixed_masks = masks[r]
+            alone = lib.dynamic_eval(a1, single, specs[r], SEQ, OVL, tok, use_tqdm=False)
             w = want[r][1 if online else 0]
-            assert got[r].shape == w.shape, (online, r, got[r].shape, w.shape)
-            d = float(np.abs(got[r] - w).max())
-            print(f"lockstep full size, {'online' if online else 'offline'}, recording {r}: max |dlogp| = {d:.2e}")
-            assert d < 1e-3, (online, r, d)
+            assert got[r].shape == w.shape == alone.shape, (online, r, got[r].shape, w.shape)
+            d, d1, dg = float(np.abs(got[r] - w).max()), float(np.abs(alone - w).max()), float(np.abs(got[r] - alone).max())
+            print(f"lockstep full size, {'online' if online else 'offline'}, recording {r}: |group - oracle| = {d:.2e}, |single - oracle| = {d1:.2e}, "
+                  f"|group - single| = {dg:.2e}")
+            assert d <= max(1e-3, 1.5 * d1) and d < 3e-3 and dg < 1e-3, (online, r, d, d1, dg)
             _argmax_check(torch.from_numpy(got[r]), torch.from_numpy(w), f"lockstep recording {r}")
