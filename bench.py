@@ -216,6 +216,11 @@ def cpu_baseline(a, hip_model, dev):
     def run(online, epochs=1):
         args = make_args(a)
         args.spec_augment_fixed_masks, args.online, args.epochs = masks, online, epochs
+        R = getattr(hip_model, "R", 1)
+        if R > 1:      # the timed path: a lockstep group — the same recording on every replica, which must then agree bit for bit
+            outs = lib.dynamic_eval_lockstep(args, hip_model, [spec.to(dev)] * R, a.seq_len, a.overlap, tok, use_tqdm=False)
+            assert all(np.array_equal(outs[0], o) for o in outs[1:]), "replicas of a lockstep group disagree on identical recordings"
+            return outs[0]
         return lib.dynamic_eval(args, hip_model, spec.to(dev), a.seq_len, a.overlap, tok, use_tqdm=False)
     got, got_online = run(False), run(True)
     band = stride // 8
@@ -571,7 +576,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             for m in models + [side_model]:                            # the parity leg runs on the bench's own (restored) weights
                 m.use_graphs = bool(a.graphs)
-            out["cpu_baseline"], out["parity"] = cpu_baseline(a, side_model, dev)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(a, model, dev)       # parity through the path that was timed (the group model when R > 1)
+            out["parity"]["path"] = f"lockstep group of {R} (identical recordings on every replica, bit-identical across replicas)" if R > 1 else "one recording per model"
         print(json.dumps(out), flush=True)
 
 
