@@ -217,11 +217,15 @@ def cpu_baseline(a, hip_model, dev):
         args = make_args(a)
         args.spec_augment_fixed_masks, args.online, args.epochs = masks, online, epochs
         R = getattr(hip_model, "R", 1)
-        if R > 1:      # the timed path: a lockstep group — the same recording on every replica, which must then agree bit for bit
+        if R > 1:      # the timed path: a lockstep group — the same recording on every replica.  The replicas are the same arithmetic up to the GEMM
+            # planner's K-slicing of the LAST partial round of tiles (those tiles belong to the last batch entries: another summation order),
+            # so they agree to rounding, not bit for bit; the spread between replicas is reported next to the distance from the oracle
             outs = lib.dynamic_eval_lockstep(args, hip_model, [spec.to(dev)] * R, a.seq_len, a.overlap, tok, use_tqdm=False)
-            assert all(np.array_equal(outs[0], o) for o in outs[1:]), "replicas of a lockstep group disagree on identical recordings"
+            if epochs:
+                spread.append(max(float(np.abs(outs[0] - o).max()) for o in outs[1:]))
             return outs[0]
         return lib.dynamic_eval(args, hip_model, spec.to(dev), a.seq_len, a.overlap, tok, use_tqdm=False)
+    spread = []
     got, got_online = run(False), run(True)
     band = stride // 8
 
@@ -249,6 +253,7 @@ def cpu_baseline(a, hip_model, dev):
               "argmax_equal": bad_off == 0 and bad_on == 0, "argmax_mismatch_frames": [bad_off, bad_on], "frames": [int(d_off.shape[0]), int(d_on.shape[0])],
               "largest_oracle_margin_at_a_mismatch": max([m for m in (m_off, m_on) if m is not None], default=None),
               "windows": len(keys), "adapt_steps_carried": len(keys),
+              "replica_spread_offline_online": [float(f"{v:.3e}") for v in spread] if spread else None,
               "online_max_abs_dlogp_per_band": [float(f"{float(d_on[k:k + band].max()):.2e}") for k in range(0, d_on.shape[0], band)],
               "band_rows": band, "words": len(hyp_o.split()), "wer_counters_hip_vs_oracle": ca, "unadapted": unadapted,
               "what": "adapted + stitched log-probs of ONE weight-carrying recording (the cpu_baseline sample): HIP path vs CPU oracle, same weights and "
