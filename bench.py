@@ -582,7 +582,7 @@ def main():
             for m in models + [side_model]:                            # the parity leg runs on the bench's own (restored) weights
                 m.use_graphs = bool(a.graphs)
             out["cpu_baseline"], out["parity"] = cpu_baseline(a, model, dev)       # parity through the path that was timed (the group model when R > 1)
-            out["parity"]["path"] = f"lockstep group of {R} (identical recordings on every replica, bit-identical across replicas)" if R > 1 else "one recording per model"
+            out["parity"]["path"] = f"lockstep group of {R} (the same recording on every replica; replicas agree to rounding: replica_spread_offline_online)" if R > 1 else "one recording per model"
         print(json.dumps(out), flush=True)
 
 
