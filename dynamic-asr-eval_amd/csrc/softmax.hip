@@ -12,8 +12,12 @@ constexpr int TPB = 256;
 
 template <int ITEMS, bool LOG>
 __global__ __launch_bounds__(TPB) void softmax_fwd_kernel(const float* x, float* y, int64_t rows, int L, int64_t ldx,
-                                                           int64_t ldy) {  // y may alias x (in-place attention softmax)
+                                                           int64_t ldy, const int32_t* __restrict__ valid) {  // y may alias x (in-place attention softmax)
     __shared__ float red[8];
+    // `valid` (device scalar, may be null): columns >= *valid are masked keys — outside the max and the sum, written as 0 (-inf for LOG).
+    // The values of the first *valid columns are bit for bit those of a row of length *valid (same per-thread items, same reductions).
+    int Lv = L;
+    if (valid) { const int v = *valid; Lv = v < 1 ? 1 : (v < L ? v : L); }
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         const float* xr = x + row * ldx;
         float v[ITEMS];
@@ -21,7 +25,7 @@ __global__ __launch_bounds__(TPB) void softmax_fwd_kernel(const float* x, float*
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const int c = threadIdx.x + j * TPB;
-            v[j] = c < L ? xr[c] : -INFINITY;
+            v[j] = c < Lv ? xr[c] : -INFINITY;
             m = fmaxf(m, v[j]);
         }
         m = dyn::block_max(m, red);
@@ -29,7 +33,7 @@ __global__ __launch_bounds__(TPB) void softmax_fwd_kernel(const float* x, float*
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const int c = threadIdx.x + j * TPB;
-            const float e = c < L ? __expf(v[j] - m) : 0.f;
+            const float e = c < Lv ? __expf(v[j] - m) : 0.f;
             s += e;
             if (!LOG) v[j] = e;
         }
@@ -112,11 +116,11 @@ __global__ __launch_bounds__(TPB) void entropy_grad_kernel(const float* __restri
 }
 
 template <bool LOG>
-int launch_fwd(const float* x, float* y, int64_t rows, int64_t L, int64_t ldx, int64_t ldy, hipStream_t st) {
+int launch_fwd(const float* x, float* y, int64_t rows, int64_t L, int64_t ldx, int64_t ldy, hipStream_t st, const int32_t* valid = nullptr) {
     int64_t g = rows < 65535 * 4 ? rows : 65535 * 4;
     dim3 grid((unsigned)g), blk(TPB);
     const int items = (int)dyn::cdiv(L, TPB);
-#define GO(I) hipLaunchKernelGGL((softmax_fwd_kernel<I, LOG>), grid, blk, 0, st, x, y, rows, (int)L, ldx, ldy)
+#define GO(I) hipLaunchKernelGGL((softmax_fwd_kernel<I, LOG>), grid, blk, 0, st, x, y, rows, (int)L, ldx, ldy, valid)
     if (items <= 1) GO(1);
     else if (items <= 2) GO(2);
     else if (items <= 4) GO(4);
@@ -152,6 +156,14 @@ extern "C" int dyn_softmax_fwd(const float* x, float* y, int64_t rows, int64_t L
     DYN_REQUIRE(x && y && rows >= 0 && L > 0 && ldx >= L && ldy >= L, DYN_E_ARG, "dyn_softmax_fwd: bad arguments");
     if (rows == 0) return DYN_OK;
     return launch_fwd<false>(x, y, rows, L, ldx, ldy, (hipStream_t)stream);
+}
+// Key-length masked softmax: `valid_cols` is a DEVICE int32 scalar read when the kernel runs (a captured launch serves every utterance
+// length of a bucket); columns >= *valid_cols get probability 0.
+extern "C" int dyn_softmax_fwd_len(const float* x, float* y, int64_t rows, int64_t L, int64_t ldx, int64_t ldy, const int32_t* valid_cols,
+                                   void* stream) {
+    DYN_REQUIRE(x && y && valid_cols && rows >= 0 && L > 0 && ldx >= L && ldy >= L, DYN_E_ARG, "dyn_softmax_fwd_len: bad arguments");
+    if (rows == 0) return DYN_OK;
+    return launch_fwd<false>(x, y, rows, L, ldx, ldy, (hipStream_t)stream, valid_cols);
 }
 extern "C" int dyn_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int64_t L, int64_t ld, float scale,
                                void* stream) {

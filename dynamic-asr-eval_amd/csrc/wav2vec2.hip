@@ -38,14 +38,22 @@ __global__ __launch_bounds__(TPB) void gelu_bwd_kernel(const float* __restrict__
 
 // ---- per-(batch, channel) normalisation over time: x [B, T, C] ----------------------------------------------------
 // stage 1: partial[(b, chunk), 0:C] = sum_t x, partial[(b, chunk), C:2C] = sum_t x^2 over the chunk's rows
+// `valid` (device scalar, may be null): only the first *valid rows of every batch entry count (a zero-padded bucket, see dyn_colnorm_fwd_len)
+__device__ __forceinline__ int64_t valid_rows(const int32_t* valid, int64_t T) {
+    if (!valid) return T;
+    const int64_t v = *valid;
+    return v < 0 ? 0 : (v < T ? v : T);
+}
+
 __global__ __launch_bounds__(TPB) void colstats_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t T,
-                                                               int C, int64_t rows_per_chunk, int chunks) {
+                                                               int C, int64_t rows_per_chunk, int chunks, const int32_t* __restrict__ valid) {
     const int c = blockIdx.x * TPB + threadIdx.x;
     const int ch = blockIdx.y;
     const int64_t b = blockIdx.z;
     if (c >= C) return;
+    const int64_t Tv = valid_rows(valid, T);
     const int64_t r0 = (int64_t)ch * rows_per_chunk;
-    const int64_t r1 = (r0 + rows_per_chunk < T) ? r0 + rows_per_chunk : T;
+    const int64_t r1 = (r0 + rows_per_chunk < Tv) ? r0 + rows_per_chunk : Tv;
     float s = 0.f, q = 0.f;
     const float* xb = x + b * T * C + c;
     for (int64_t t = r0; t < r1; ++t) {
@@ -60,10 +68,13 @@ __global__ __launch_bounds__(TPB) void colstats_partial_kernel(const float* __re
 
 // stage 2 (per batch): mean/rstd [B, C] from the chunk partials, summed in chunk order
 __global__ __launch_bounds__(TPB) void colstats_final_kernel(const float* __restrict__ partial, float* __restrict__ mean,
-                                                             float* __restrict__ rstd, int64_t T, int C, int chunks, float eps) {
+                                                             float* __restrict__ rstd, int64_t T, int C, int chunks, float eps,
+                                                             const int32_t* __restrict__ valid) {
     const int c = blockIdx.x * TPB + threadIdx.x;
     const int64_t b = blockIdx.y;
     if (c >= C) return;
+    T = valid_rows(valid, T);
+    if (T < 1) T = 1;
     double s = 0.0, q = 0.0;
     for (int ch = 0; ch < chunks; ++ch) {
         const float* p = partial + ((b * chunks + ch) * 2) * C;
@@ -93,13 +104,14 @@ __global__ __launch_bounds__(TPB) void colnorm_apply_kernel(const float* __restr
 __global__ __launch_bounds__(TPB) void colnorm_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                   float* __restrict__ partial, int64_t T, int C,
-                                                                  int64_t rows_per_chunk, int chunks) {
+                                                                  int64_t rows_per_chunk, int chunks, const int32_t* __restrict__ valid) {
     const int c = blockIdx.x * TPB + threadIdx.x;
     const int ch = blockIdx.y;
     const int64_t b = blockIdx.z;
     if (c >= C) return;
+    const int64_t Tv = valid_rows(valid, T);
     const int64_t r0 = (int64_t)ch * rows_per_chunk;
-    const int64_t r1 = (r0 + rows_per_chunk < T) ? r0 + rows_per_chunk : T;
+    const int64_t r1 = (r0 + rows_per_chunk < Tv) ? r0 + rows_per_chunk : Tv;
     const float m = mean[b * C + c], rs = rstd[b * C + c];
     float s1 = 0.f, s2 = 0.f;
     for (int64_t t = r0; t < r1; ++t) {
@@ -134,12 +146,15 @@ __global__ __launch_bounds__(TPB) void colnorm_bwd_sums_kernel(const float* __re
 __global__ __launch_bounds__(TPB) void colnorm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                                float* __restrict__ dx, int64_t B, int64_t T, int C) {
+                                                                float* __restrict__ dx, int64_t B, int64_t T, int C,
+                                                                const int32_t* __restrict__ valid) {
     const int64_t total = B * T * C;
-    const float invT = 1.f / (float)T;
+    const int64_t Tv = valid_rows(valid, T);
+    const float invT = 1.f / (float)(Tv > 0 ? Tv : 1);
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
         const int c = (int)(i % C);
         const int64_t b = i / (T * C);
+        if ((i / C) % T >= Tv) { dx[i] = 0.f; continue; }   // a padded row took no part in the statistics: no gradient
         const float rs = rstd[b * C + c];
         const float xh = (x[i] - mean[b * C + c]) * rs;
         const float s1 = sums[(0 * B + b) * C + c] * invT, s2 = sums[(1 * B + b) * C + c] * invT;
@@ -164,6 +179,14 @@ __global__ __launch_bounds__(TPB) void col2im_kernel(const float* __restrict__ d
         }
         dx[i] = s;
     }
+}
+
+// x[b, t, :] = 0 for t >= *valid  (the padded tail of a bucket must look like the zero padding the positional conv sees past the last frame)
+__global__ __launch_bounds__(TPB) void mask_rows_kernel(float* __restrict__ x, int64_t B, int64_t T, int C, const int32_t* __restrict__ valid) {
+    const int64_t Tv = valid_rows(valid, T);
+    const int64_t tail = (T - Tv) * C, total = B * tail;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB)
+        x[(i / tail) * T * C + Tv * C + i % tail] = 0.f;
 }
 
 // ---- grouped positional conv: [B, T, C] <-> [B, G, T + 2 pad, C/G] (zero padded) ----------------------------------
@@ -310,8 +333,12 @@ extern "C" int64_t dyn_colnorm_workspace_bytes(int64_t B, int64_t T, int64_t C) 
     return ((int64_t)B * chunks_for(T, &per) * 2 * C + (int64_t)B * 2 * C) * (int64_t)sizeof(float);
 }
 
-extern "C" int dyn_colnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t B,
-                               int64_t T, int64_t C, float eps, void* workspace, int64_t workspace_bytes, void* stream) {
+// `valid_rows`: null, or a DEVICE int32 scalar read when the kernels run — statistics over the first *valid_rows rows of every batch entry
+// (rows past it are normalised with the same statistics: finite, meaningless).  One captured launch sequence serves every utterance length of
+// a bucket this way (wav2vec2_model.py: the length lives in HBM, not in the launch arguments).
+extern "C" int dyn_colnorm_fwd_len(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t B,
+                                   int64_t T, int64_t C, float eps, const int32_t* valid_rows, void* workspace, int64_t workspace_bytes,
+                                   void* stream) {
     DYN_REQUIRE(x && gamma && beta && y && mean && rstd && B > 0 && T > 0 && C > 0, DYN_E_ARG, "dyn_colnorm_fwd: bad arguments");
     DYN_REQUIRE(workspace && workspace_bytes >= dyn_colnorm_workspace_bytes(B, T, C), DYN_E_WORKSPACE, "dyn_colnorm_fwd: workspace too small");
     int64_t per;
@@ -319,16 +346,21 @@ extern "C" int dyn_colnorm_fwd(const float* x, const float* gamma, const float* 
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)workspace;
     hipLaunchKernelGGL(colstats_partial_kernel, dim3((unsigned)dyn::cdiv(C, TPB), (unsigned)chunks, (unsigned)B), dim3(TPB), 0, st, x, partial,
-                       T, (int)C, per, chunks);
+                       T, (int)C, per, chunks, valid_rows);
     hipLaunchKernelGGL(colstats_final_kernel, dim3((unsigned)dyn::cdiv(C, TPB), (unsigned)B), dim3(TPB), 0, st, partial, mean, rstd, T, (int)C,
-                       chunks, eps);
+                       chunks, eps, valid_rows);
     hipLaunchKernelGGL(colnorm_apply_kernel, dim3(grid_for(B * T * C)), dim3(TPB), 0, st, x, mean, rstd, gamma, beta, y, B, T, (int)C);
     return dyn::check_launch("dyn_colnorm_fwd");
 }
+extern "C" int dyn_colnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t B,
+                               int64_t T, int64_t C, float eps, void* workspace, int64_t workspace_bytes, void* stream) {
+    return dyn_colnorm_fwd_len(x, gamma, beta, y, mean, rstd, B, T, C, eps, nullptr, workspace, workspace_bytes, stream);
+}
 
-extern "C" int dyn_colnorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
-                               float* dgamma, float* dbeta, float wgrad_beta, int64_t B, int64_t T, int64_t C, void* workspace,
-                               int64_t workspace_bytes, void* stream) {
+// `valid_rows` as in dyn_colnorm_fwd_len: sums over the valid rows only, dx = 0 on the rows past them.
+extern "C" int dyn_colnorm_bwd_len(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
+                                   float* dgamma, float* dbeta, float wgrad_beta, int64_t B, int64_t T, int64_t C, const int32_t* valid_rows,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
     DYN_REQUIRE(x && gamma && mean && rstd && dy && dx && B > 0 && T > 0 && C > 0, DYN_E_ARG, "dyn_colnorm_bwd: bad arguments");
     DYN_REQUIRE(workspace && workspace_bytes >= dyn_colnorm_workspace_bytes(B, T, C), DYN_E_WORKSPACE, "dyn_colnorm_bwd: workspace too small");
     int64_t per;
@@ -337,14 +369,27 @@ extern "C" int dyn_colnorm_bwd(const float* x, const float* gamma, const float* 
     float* partial = (float*)workspace;
     float* sums = partial + (int64_t)B * chunks * 2 * C;  // [B, 2, C]
     hipLaunchKernelGGL(colnorm_bwd_partial_kernel, dim3((unsigned)dyn::cdiv(C, TPB), (unsigned)chunks, (unsigned)B), dim3(TPB), 0, st, x, dy,
-                       mean, rstd, partial, T, (int)C, per, chunks);
+                       mean, rstd, partial, T, (int)C, per, chunks, valid_rows);
     hipLaunchKernelGGL(colnorm_bwd_sums_kernel, dim3((unsigned)dyn::cdiv(C, TPB), (unsigned)B), dim3(TPB), 0, st, partial, sums, (int)C, chunks);
-    hipLaunchKernelGGL(colnorm_bwd_apply_kernel, dim3(grid_for(B * T * C)), dim3(TPB), 0, st, x, dy, mean, rstd, gamma, sums, dx, B, T, (int)C);
+    hipLaunchKernelGGL(colnorm_bwd_apply_kernel, dim3(grid_for(B * T * C)), dim3(TPB), 0, st, x, dy, mean, rstd, gamma, sums, dx, B, T, (int)C,
+                       valid_rows);
     // sums is [2][B][C]: reduce over the batch (in order) into the affine gradients
     dyn::ordered_before_launch(st);
     if (dbeta) dyn::launch_reduce_partials(sums, dbeta, B, C, wgrad_beta, st);
     if (dgamma) dyn::launch_reduce_partials(sums + (int64_t)B * C, dgamma, B, C, wgrad_beta, st);
     return dyn::check_launch("dyn_colnorm_bwd");
+}
+extern "C" int dyn_colnorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
+                               float* dgamma, float* dbeta, float wgrad_beta, int64_t B, int64_t T, int64_t C, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    return dyn_colnorm_bwd_len(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, wgrad_beta, B, T, C, nullptr, workspace, workspace_bytes, stream);
+}
+
+// x [B, T, C]: rows t >= *valid_rows (device int32 scalar) of every batch entry are set to zero, the others are not touched.
+extern "C" int dyn_mask_rows(float* x, int64_t B, int64_t T, int64_t C, const int32_t* valid_rows, void* stream) {
+    DYN_REQUIRE(x && valid_rows && B > 0 && T > 0 && C > 0, DYN_E_ARG, "dyn_mask_rows: bad arguments");
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for(B * T * C)), dim3(TPB), 0, (hipStream_t)stream, x, B, T, (int)C, valid_rows);
+    return dyn::check_launch("dyn_mask_rows");
 }
 
 extern "C" int64_t dyn_weight_norm_workspace_bytes(int64_t rows, int64_t kw) {

@@ -657,10 +657,14 @@ def _rows_L(x):
     return x.numel() // L, L
 
 
-def softmax(x, out=None):
+def softmax(x, out=None, valid=None):
+    """Row softmax; `valid` (device int32 scalar): columns >= valid are masked keys (probability 0)."""
     _cc(x, "softmax.x")
     rows, L = _rows_L(x)
     out = torch.empty_like(x) if out is None else _cc(out, "softmax.out")
+    if valid is not None:
+        check(_L().dyn_softmax_fwd_len(x.data_ptr(), out.data_ptr(), rows, L, L, L, _valid_ptr(valid, "softmax"), _stream()), "dyn_softmax_fwd_len")
+        return out
     check(_L().dyn_softmax_fwd(x.data_ptr(), out.data_ptr(), rows, L, L, L, _stream()), "dyn_softmax_fwd")
     return out
 
@@ -997,26 +1001,45 @@ def gelu_bwd(x, dy, out=None):
     return out
 
 
-def colnorm(x, gamma, beta, eps=1e-5):
-    """x [B, T, C]: normalise over T per (b, c) (GroupNorm with groups == channels). Returns (y, mean, rstd)."""
+def _valid_ptr(valid, what):
+    """`valid`: None, or a one-element int32 CUDA tensor holding a row / column count that the kernel reads when it RUNS (so a captured launch
+    follows later updates of the tensor)."""
+    if valid is None:
+        return None
+    if not (isinstance(valid, torch.Tensor) and valid.is_cuda and valid.dtype == torch.int32 and valid.numel() == 1):
+        raise DynError(f"{what}: the valid-length operand must be a one-element int32 CUDA tensor")
+    return valid.data_ptr()
+
+
+def colnorm(x, gamma, beta, eps=1e-5, valid=None):
+    """x [B, T, C]: normalise over T per (b, c) (GroupNorm with groups == channels). Returns (y, mean, rstd).  `valid` (device int32 scalar):
+    the statistics cover the first `valid` rows only (zero-padded bucket)."""
     _c(x, "colnorm.x")
     B, T, C = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(B, C, device=x.device, dtype=F32); rstd = torch.empty(B, C, device=x.device, dtype=F32)
     ws = workspace(x.device)
-    check(_L().dyn_colnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, T, C,
-                               eps, ws.data_ptr(), ws.numel(), _stream()), "dyn_colnorm_fwd")
+    check(_L().dyn_colnorm_fwd_len(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, T, C,
+                                   eps, _valid_ptr(valid, "colnorm"), ws.data_ptr(), ws.numel(), _stream()), "dyn_colnorm_fwd")
     return y, mean, rstd
 
 
-def colnorm_bwd(x, gamma, mean, rstd, dy, dgamma, dbeta, wgrad_beta=1.0):
+def colnorm_bwd(x, gamma, mean, rstd, dy, dgamma, dbeta, wgrad_beta=1.0, valid=None):
     B, T, C = x.shape
     dx = torch.empty_like(x)
     ws = workspace(x.device)
-    check(_L().dyn_colnorm_bwd(x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(),
-                               _opt(dgamma, "dgamma"), _opt(dbeta, "dbeta"), wgrad_beta, B, T, C, ws.data_ptr(), ws.numel(), _stream()),
-          "dyn_colnorm_bwd")
+    check(_L().dyn_colnorm_bwd_len(x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(),
+                                   _opt(dgamma, "dgamma"), _opt(dbeta, "dbeta"), wgrad_beta, B, T, C, _valid_ptr(valid, "colnorm_bwd"),
+                                   ws.data_ptr(), ws.numel(), _stream()), "dyn_colnorm_bwd")
     return dx
+
+
+def mask_rows(x, valid):
+    """x [B, T, C] in place: rows t >= valid (device int32 scalar) of every batch entry := 0."""
+    _cc(x, "mask_rows.x")
+    B, T, C = x.shape
+    check(_L().dyn_mask_rows(x.data_ptr(), B, T, C, _valid_ptr(valid, "mask_rows"), _stream()), "dyn_mask_rows")
+    return x
 
 
 def conv1d_out_len(T, kw, stride):

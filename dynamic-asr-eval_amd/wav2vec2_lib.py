@@ -105,6 +105,10 @@ def dynamic_eval_ctc_loss_su(args, model, utterances, seq_len, overlap, tokenize
     decoder = GreedyCTCDecoder(tokenizer=tokenizer, blank_id=blank, device=device)
     assert overlap / downsampling_factor == overlap // downsampling_factor, 'Overlap must be a multiple of the downsampling factor'
     model = disable_dropout(model)
+    # hipGraph replay over utterance-length buckets (wav2vec2_model.py::forward): `args.use_graphs` (default on), `args.bucket_frames`
+    was_graphs = model.use_graphs
+    model.use_graphs = bool(args.__dict__.get('use_graphs', True))
+    model.bucket_frames = int(args.__dict__.get('bucket_frames', model.bucket_frames))
     for epoch in range(args.__dict__.get('epochs', 1)):
         indexes = list(range(len(utterances)))
         indexes = random.sample(indexes, len(indexes)) if args.__dict__.get('shuffle', False) else indexes
@@ -114,15 +118,16 @@ def dynamic_eval_ctc_loss_su(args, model, utterances, seq_len, overlap, tokenize
             audio_chunk = wav.reshape(1, -1).repeat(num_negatives + 1, 1).contiguous()          # [B, L]
             input_values = normalize_waveform(audio_chunk)
             with torch.enable_grad():
-                logits = model(input_values).logits
-            log_p = ops.log_softmax(logits)                                                      # F.log_softmax, lib.py:417
-            pseudo_targets = decoder(log_p[-1])
+                out = model(input_values)
+            log_p = ops.log_softmax(out.logits)                                                  # F.log_softmax, lib.py:417
+            N = out.frames                      # < log_p.shape[1] when the utterance ran zero-padded in its length bucket: the frames past N are not its own
+            pseudo_targets = decoder(log_p[-1, :N])
             ids = tokenizer(pseudo_targets).input_ids
             S = len(ids)
             targets = torch.tensor([ids if S else [0]] * num_negatives, dtype=torch.int32, device=device)
             aug = log_p[:num_negatives].contiguous()
-            N, B = aug.shape[1], aug.shape[0]
-            ilen = torch.full((B,), N, dtype=torch.int32, device=device)
+            B = aug.shape[0]
+            ilen = torch.full((B,), N, dtype=torch.int32, device=device)                         # CTC over the utterance's own frames; zero gradient past them
             tlen = torch.full((B,), S, dtype=torch.int32, device=device)
             _, _, g_lp = ops.ctc_loss(aug, targets, ilen, tlen, blank, reduction="mean", grad_scale=1.0)   # lib.py:351,434
             g_logits = ops.log_softmax_bwd(aug, g_lp)
@@ -130,8 +135,9 @@ def dynamic_eval_ctc_loss_su(args, model, utterances, seq_len, overlap, tokenize
             ops.clip_grad_norm(model.flat_grads, 10.0)                                           # lib.py:442
             optimizer.step()
             optimizer.zero_grad()
-            utterances[idx]['probs'] = log_p[-1].detach().cpu()
+            utterances[idx]['probs'] = log_p[-1, :N].detach().cpu()
     model.flat_params.copy_(original)                                                            # lib.py:459-460
+    model.use_graphs = was_graphs
     return utterances
 
 
@@ -163,6 +169,9 @@ def dynamic_eval_ctc_loss(args, model, spec, seq_len, overlap, tokenizer, proces
         last_ulen = u_len
         training_data[i] = chunk
     outputs = {}
+    was_graphs = model.use_graphs
+    model.use_graphs = bool(args.__dict__.get('use_graphs', True))      # every full window falls into one length bucket: captured once, replayed
+    model.bucket_frames = int(args.__dict__.get('bucket_frames', model.bucket_frames))
     for epoch in range(args.__dict__.get('epochs', 1)):
         outputs = {}
         keys = list(training_data.keys())
@@ -176,20 +185,21 @@ def dynamic_eval_ctc_loss(args, model, spec, seq_len, overlap, tokenizer, proces
                     wav_augment_chunk(audio[j])
             input_values = normalize_waveform(audio)
             with torch.enable_grad():
-                logits = model(input_values).logits
-            log_p = ops.log_softmax(logits)
-            ids = tokenizer(decoder(log_p[-1])).input_ids
+                out = model(input_values)
+            log_p = ops.log_softmax(out.logits)
+            N = out.frames                                                                      # the window's own frames (see dynamic_eval_ctc_loss_su)
+            ids = tokenizer(decoder(log_p[-1, :N])).input_ids
             S = len(ids)
             targets = torch.tensor([ids if S else [0]] * num_negatives, dtype=torch.int32, device=device)
             aug = log_p[:num_negatives].contiguous()
-            N, B = aug.shape[1], aug.shape[0]
+            B = aug.shape[0]
             ilen = torch.full((B,), N, dtype=torch.int32, device=device); tlen = torch.full((B,), S, dtype=torch.int32, device=device)
             _, _, g_lp = ops.ctc_loss(aug, targets, ilen, tlen, blank, reduction="sum", grad_scale=1.0 / (N * B))
             optimizer.zero_grad()
             model.backward(ops.log_softmax_bwd(aug, g_lp), n_active=num_negatives)
             optimizer.step()
-            ds_len = log_p.shape[1]
-            outputs[i] = (log_p[-1].detach(), ds_len, int(overlap / (u_len / ds_len)))
+            ds_len = N
+            outputs[i] = (log_p[-1, :N], ds_len, int(overlap / (u_len / ds_len)))
     pos = end = 0
     for i in sorted(outputs):
         lp, ds_len, ov = outputs[i]
@@ -199,6 +209,7 @@ def dynamic_eval_ctc_loss(args, model, spec, seq_len, overlap, tokenizer, proces
         end = max(end, pos)
     logits = ops.stitch_finalize(acc, cnt, end)
     model.flat_params.copy_(original)
+    model.use_graphs = was_graphs
     return logits if return_device else logits.cpu().numpy()
 
 

@@ -11,11 +11,13 @@ of conv kernels is [C_out][kernel][C_in] so each strided Conv1d is one implicit 
 channels-last activation (ops.conv1d), converted on load / save."""
 import math
 import os
+from collections import OrderedDict
 from types import SimpleNamespace
 
 import torch
 
 from . import ops
+from .model import _capture_guard, _no_gc
 from .optim import ParamList
 
 DEFAULT_CONFIG = dict(
@@ -112,6 +114,17 @@ class Wav2Vec2ForCTC:
         self._wq = None
         self.grouped_wgrad = os.environ.get("DYN_GROUPED_WGRAD", "1") != "0"     # A/B switch: 0 = one launch per weight gradient
         self.config = SimpleNamespace(**c)
+        # hipGraph replay over LENGTH BUCKETS (see forward()): off unless a loop turns it on (wav2vec2_lib: args.use_graphs)
+        self.use_graphs = False
+        self.bucket_frames = 32                  # an utterance of T' frames runs in the bucket of ceil(T' / 32) * 32 frames (0.64 s of audio)
+        self.graph_after = 2                     # a bucket is captured the n-th time it is seen; before that the utterance runs unpadded, eagerly
+        self.graph_budget_bytes = 96 << 30       # device memory the buckets' graphs (saved activations + temporaries) may hold; least recently used go first
+        self._graphs = OrderedDict()             # bucket key -> {"graph", "in", "out", "ctx", "pool", "bwd": {...}, "bytes"}
+        self._seen = {}
+        self._valid = None                       # device int32 [n_conv]: valid frames after every conv layer of the utterance in flight
+        self._vl = None                          # = self._valid while a bucketed launch sequence is being issued / captured, else None
+        self._ws = None
+        self._ctx_static, self._ctx_key = False, None
 
     # ------------------------------------------------------------------ nn.Module-like surface
     def named_parameters(self):
@@ -169,12 +182,122 @@ class Wav2Vec2ForCTC:
     def __call__(self, input_values, **kw):
         return self.forward(input_values)
 
+    def conv_lengths(self, L):
+        """Frames after every layer of the feature extractor for L input samples."""
+        out = []
+        for k, st in zip(self.cfg["conv_kernel"], self.cfg["conv_stride"]):
+            L = (L - k) // st + 1
+            out.append(L)
+        return out
+
+    def samples_for_frames(self, T):
+        """The smallest number of input samples that gives T output frames."""
+        L = T
+        for k, st in zip(reversed(self.cfg["conv_kernel"]), reversed(self.cfg["conv_stride"])):
+            L = (L - 1) * st + k
+        return L
+
+    def _scratch(self):
+        if self._ws is None:        # the model's own scratch (ops.use_workspace): a stream-keyed buffer is wrong inside a capture
+            self._ws = torch.empty(ops.WORKSPACE_BYTES, dtype=torch.uint8, device=self.device)
+            ops.counters(self._ws)
+            self._valid = torch.zeros(len(self.cfg["conv_kernel"]), dtype=torch.int32, device=self.device)
+        return self._ws
+
     def forward(self, input_values):
-        """input_values [B, L] float32 on the device (already zero-mean / unit-variance) -> SimpleNamespace(logits [B, T', V])."""
+        """input_values [B, L] float32 on the device (already zero-mean / unit-variance) -> SimpleNamespace(logits [B, T', V], frames).
+
+        With `use_graphs` the launch sequence of a LENGTH BUCKET is captured once as a hipGraph and replayed for every utterance that
+        falls into it (the per-utterance loop, reference wav2vec2/lib.py:293-462, is launch-bound — ~500 launches
+        of work for ~10 ms of audio model time, and every utterance has its own length).  The waveform is zero-padded to the bucket's
+        sample count; `logits` then has the BUCKET's frame count and `frames` says how many of them belong to the utterance.  The
+        utterance's own frame counts live in HBM (`_valid`) and are read by the kernels when the graph runs, so that the valid frames
+        are those of the unpadded run: the first layer's GroupNorm takes its statistics over the valid frames only
+        (dyn_colnorm_fwd_len), the frames past the end are zeroed before the positional conv (dyn_mask_rows: what its zero padding
+        holds there), and attention masks the keys past the end (dyn_softmax_fwd_len).  Everything else is per frame, or (the strided
+        convs) looks only backwards from a valid frame.  The backward gets exact zeros on the padded frames (CTC gives them zero
+        gradient, every per-frame kernel maps 0 to 0, the masked softmax cuts the attention path, dyn_mask_rows / dyn_colnorm_bwd_len
+        cut the other two), so every weight gradient sums the same terms plus zeros: equal to the unpadded run up to the summation
+        order of a longer K (tests/test_wav2vec2_gpu.py)."""
         x = input_values
         if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
             raise ops.DynError("input_values must be a float32 CUDA tensor [B, L]")
+        with ops.use_workspace(self._scratch()):
+            if self.use_graphs and not ops.GEMM_PROFILE_EAGER():
+                return self._forward_bucketed(x)
+            self._vl, self._ctx_static = None, False
+            return self._forward_eager(x)
+
+    def _bucket(self, L):
+        T = self.conv_lengths(L)[-1]
+        q = max(1, int(self.bucket_frames))
+        Tb = -(-T // q) * q
+        return T, Tb, self.samples_for_frames(Tb + 1) - 1       # every L with <= Tb frames fits; the bucket itself has exactly Tb frames
+
+    def graph_bytes(self):
+        return sum(e["bytes"] for e in self._graphs.values())
+
+    def drop_graphs(self):
+        """Forget every captured bucket (frees their activations)."""
+        budget, self.graph_budget_bytes = self.graph_budget_bytes, -1
+        self._evict()
+        self.graph_budget_bytes = budget
+
+    def _evict(self, keep=None):
+        """Drop least-recently-used buckets until the budget holds (never inside a capture: destroying a graph there aborts the process)."""
+        while self._graphs and self.graph_bytes() > self.graph_budget_bytes:
+            key = next(iter(self._graphs))
+            if key == keep:
+                break
+            torch.cuda.synchronize(self.device)             # no replay of the bucket may still be in flight when its graphs are destroyed
+            ent = self._graphs.pop(key)
+            if self._ctx is ent["ctx"]:
+                self._ctx, self._ctx_static = None, False
+            ent.clear()
+
+    def _forward_bucketed(self, x):
+        B, L = x.shape
+        need = self.samples_for_frames(1)
+        if L < need:
+            raise ops.DynError(f"input of {L} samples is shorter than the feature extractor's receptive field ({need} samples)")
+        T, Tb, Lb = self._bucket(L)
+        key = (B, Lb, torch.is_grad_enabled())
+        ent = self._graphs.get(key)
+        if ent is None:
+            n = self._seen[key] = self._seen.get(key, 0) + 1
+            if n < self.graph_after:
+                self._vl, self._ctx_static = None, False
+                return self._forward_eager(x)
+            self._evict()
+            r0 = torch.cuda.memory_reserved(self.device)
+            static_in = torch.zeros(B, Lb, device=self.device, dtype=torch.float32)
+            pool = torch.cuda.graph_pool_handle()       # one pool per bucket: its forward and backward alternate strictly (model.py::_graph_pool)
+            graph = torch.cuda.CUDAGraph()
+            prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+            self._vl = self._valid
+            try:
+                with _no_gc(), torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"), _capture_guard():
+                    out = self._forward_eager(static_in)
+            finally:
+                ops.GEMM_PROFILE, self._vl = prof, None
+            ent = {"graph": graph, "in": static_in, "out": out.logits, "ctx": self._ctx, "pool": pool, "bwd": {}, "len": 0,
+                   "bytes": max(0, torch.cuda.memory_reserved(self.device) - r0)}
+            self._graphs[key] = ent
+        self._graphs.move_to_end(key)
+        ent["in"][:, :L].copy_(x)
+        if L < ent["len"]:
+            ent["in"][:, L:ent["len"]].zero_()
+        ent["len"] = L                                   # (beyond the previous utterance's end the buffer is still zero)
+        self._valid.copy_(torch.tensor(self.conv_lengths(L), dtype=torch.int32))
+        ent["graph"].replay()
+        self._ctx, self._ctx_static, self._ctx_key = ent["ctx"], True, key
+        return SimpleNamespace(logits=ent["out"], frames=T)
+
+    def _forward_eager(self, x):
         c, P = self.cfg, self.P
+        vl = self._vl
+        v0 = vl[0:1] if vl is not None else None             # valid frames after the first conv (its GroupNorm runs over time)
+        vT = vl[-1:] if vl is not None else None             # valid frames of the encoder
         save = torch.is_grad_enabled()
         ctx = {"conv": []} if save else None
         B, L = x.shape
@@ -189,7 +312,7 @@ class Wav2Vec2ForCTC:
             w = P[f"{fe}{i}.conv.weight"]
             z = ops.conv1d(a, w.view(w.shape[0], -1), k, s)
             if i == 0:
-                n0, mean, rstd = ops.colnorm(z, P[fe + "0.layer_norm.weight"], P[fe + "0.layer_norm.bias"], c["layer_norm_eps"])
+                n0, mean, rstd = ops.colnorm(z, P[fe + "0.layer_norm.weight"], P[fe + "0.layer_norm.bias"], c["layer_norm_eps"], valid=v0)
                 act = ops.gelu(n0)
                 if save:
                     ctx["conv"].append((a, z, (mean, rstd, n0)))
@@ -202,6 +325,8 @@ class Wav2Vec2ForCTC:
         fp = "wav2vec2.feature_projection."
         n, mean, rstd = ops.layernorm(a, P[fp + "layer_norm.weight"], P[fp + "layer_norm.bias"], c["layer_norm_eps"])
         h = ops.linear(n, P[fp + "projection.weight"], P[fp + "projection.bias"])
+        if vT is not None:
+            ops.mask_rows(h, vT)                                    # the positional conv must see zeros past the utterance's last frame
         if save:
             ctx["proj"] = (a, mean, rstd, n)
         # positional conv embedding (grouped, weight-normed), GELU, residual, LayerNorm
@@ -237,7 +362,7 @@ class Wav2Vec2ForCTC:
             S = torch.empty(B, nh, T, T, device=h.device, dtype=torch.float32)
             ops.gemm(qkv, qkv, S, trans_b=True, M=T, N=T, K=D, lda=3 * H, ldb=3 * H, ldc=T, nb1=B, nb2=nh,
                      sa=(T * 3 * H, D), sb=(T * 3 * H, D), sc=(nh * T * T, T * T), b_off=H, alpha=D ** -0.5)
-            ops.softmax(S, out=S)
+            ops.softmax(S, out=S, valid=vT)
             O = torch.empty(B, T, H, device=h.device, dtype=torch.float32)
             ops.gemm(S, qkv, O, M=T, N=D, K=T, lda=T, ldb=3 * H, ldc=H, nb1=B, nb2=nh, sa=(nh * T * T, T * T),
                      sb=(T * 3 * H, D), sc=(T * H, D), b_off=2 * H)
@@ -256,8 +381,9 @@ class Wav2Vec2ForCTC:
         if save:
             ctx["head"] = h
             ctx["dims"] = (B, L, T)
+            ctx["valid"] = (v0, vT)
         self._ctx = ctx
-        return SimpleNamespace(logits=logits)
+        return SimpleNamespace(logits=logits, frames=T)
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, dy, x, dw, db):
@@ -280,6 +406,33 @@ class Wav2Vec2ForCTC:
         column reductions of the norm / bias gradients run as one batched launch at the end (ops.reduce_defer; bit-identical)."""
         if self._defer_arena is None and os.environ.get("DYN_DEFER_REDUCE", "1") != "0":
             self._defer_arena = torch.empty(ops.DEFER_ARENA_BYTES, dtype=torch.uint8, device=self.device)
+        with ops.use_workspace(self._scratch()):
+            if self._ctx_static and self.use_graphs and self._ctx is not None:
+                return self._backward_graphed(grad_logits, n_active)
+            self._backward_eager(grad_logits, n_active)
+
+    def _backward_graphed(self, grad_logits, n_active):
+        """Replay (first use: capture) of the backward launch sequence of the bucket whose forward graph produced the saved activations."""
+        ent = self._graphs[self._ctx_key]
+        key = (tuple(grad_logits.shape), n_active, frozenset(self.frozen), self.grouped_wgrad)
+        b = ent["bwd"].get(key)
+        if b is None:
+            r0 = torch.cuda.memory_reserved(self.device)
+            static_g = grad_logits.contiguous().clone()
+            graph = torch.cuda.CUDAGraph()
+            prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+            try:
+                with _no_gc(), torch.cuda.graph(graph, pool=ent["pool"], capture_error_mode="thread_local"), _capture_guard():
+                    self._backward_eager(static_g, n_active)
+            finally:
+                ops.GEMM_PROFILE = prof
+            b = ent["bwd"][key] = {"graph": graph, "g": static_g}
+            ent["bytes"] += max(0, torch.cuda.memory_reserved(self.device) - r0)
+        b["g"].copy_(grad_logits)
+        b["graph"].replay()
+        self._ctx = None
+
+    def _backward_eager(self, grad_logits, n_active):
         with ops.reduce_defer(self._defer_arena):
             self._backward_body(grad_logits, n_active)
         for name in self.frozen:                    # after the deferred reductions have been queued: they write gradients too
@@ -300,6 +453,10 @@ class Wav2Vec2ForCTC:
         ctx = self._ctx
         if ctx is None:
             raise ops.DynError("backward() without a grad-mode forward")
+        if self._ctx_static:                        # a graph-owned context must survive the backward (entries are dropped below as they are used)
+            ctx = dict(ctx)
+            ctx["layers"], ctx["conv"] = list(ctx["layers"]), list(ctx["conv"])
+        v0, vT = ctx["valid"]
         c, P, G = self.cfg, self.P, self.G
         B, L, T = ctx["dims"]
         nb = B if n_active is None else int(n_active)
@@ -385,6 +542,8 @@ class Wav2Vec2ForCTC:
         check(load().dyn_col2im_1d(dA.data_ptr(), dxg.data_ptr(), nb * Gn, Tp, T, cg, K, 1, torch.cuda.current_stream().cuda_stream),
               "dyn_col2im_1d")
         ops.group_unpack_grad(dxg.view(nb, Gn, Tp, cg), dhs, pad, beta=1.0)   # dh (pre-pos) = dhs (residual) + pos-conv path
+        if vT is not None:
+            ops.mask_rows(dhs, vT)                                   # the windows of the last valid frames reach into the zeroed tail: no gradient there
         # feature projection
         a, mean, rstd, n = cut(ctx["proj"])
         fp = "wav2vec2.feature_projection."
@@ -401,7 +560,8 @@ class Wav2Vec2ForCTC:
             if i == 0:
                 mean, rstd, n0 = norm
                 dn0 = ops.gelu_bwd(n0, da)
-                dz = ops.colnorm_bwd(z, P[fe + "0.layer_norm.weight"], mean, rstd, dn0, G[fe + "0.layer_norm.weight"], G[fe + "0.layer_norm.bias"])
+                dz = ops.colnorm_bwd(z, P[fe + "0.layer_norm.weight"], mean, rstd, dn0, G[fe + "0.layer_norm.weight"], G[fe + "0.layer_norm.bias"],
+                                     valid=v0)
             else:
                 dz = ops.gelu_bwd(z, da)
             ops.conv1d_wgrad(a_in, dz, G[wname].view(wmat.shape), k, s, beta=1.0)

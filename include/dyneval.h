@@ -170,6 +170,12 @@ int dyn_chanaffine_bwd(const float* x, const float* mean, const float* var, cons
 int dyn_softmax_fwd(const float* x, float* y, int64_t rows, int64_t L, int64_t ldx, int64_t ldy, void* stream);
 int dyn_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int64_t L, int64_t ld, float scale,
                     void* stream);
+/* Key-length masked softmax (the attention of a zero-padded utterance bucket, wav2vec2_model.py; HF passes no attention mask to
+ * wav2vec2-base, reference wav2vec2/lib.py:413, so an utterance attends to exactly its own frames): `valid_cols` is a DEVICE int32
+ * scalar read when the kernel runs; columns >= *valid_cols are outside the max / sum and get probability 0, the first *valid_cols
+ * values are bit for bit those of a row of that length. */
+int dyn_softmax_fwd_len(const float* x, float* y, int64_t rows, int64_t L, int64_t ldx, int64_t ldy, const int32_t* valid_cols,
+                        void* stream);
 int dyn_log_softmax_fwd(const float* x, float* y, int64_t rows, int64_t L, int64_t ldx, int64_t ldy, void* stream);
 int dyn_log_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int64_t L, int64_t ld, void* stream);
 /* Gradient of the mean categorical entropy w.r.t. the log-probabilities (the `entropy_augmentation` input perturbation,
@@ -459,6 +465,18 @@ int dyn_colnorm_fwd(const float* x, const float* gamma, const float* beta, float
 int dyn_colnorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
                     float* dgamma, float* dbeta, float wgrad_beta, int64_t B, int64_t T, int64_t C, void* workspace,
                     int64_t workspace_bytes, void* stream);
+/* The same with a DEVICE-side row count (`valid_rows`: null = all T rows, else an int32 scalar in HBM read when the kernels run):
+ * statistics / sums over the first *valid_rows rows of every batch entry, dx = 0 past them.  With dyn_mask_rows and
+ * dyn_softmax_fwd_len this lets one captured launch sequence (hipGraph) serve every utterance length of a zero-padded bucket of the
+ * per-utterance loop (reference wav2vec2/lib.py:293-462 runs each utterance at its own length). */
+int dyn_colnorm_fwd_len(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t B,
+                        int64_t T, int64_t C, float eps, const int32_t* valid_rows, void* workspace, int64_t workspace_bytes,
+                        void* stream);
+int dyn_colnorm_bwd_len(const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
+                        float* dgamma, float* dbeta, float wgrad_beta, int64_t B, int64_t T, int64_t C, const int32_t* valid_rows,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+/* x [B, T, C]: rows t >= *valid_rows of every batch entry := 0 (what the positional conv's zero padding holds past the last frame). */
+int dyn_mask_rows(float* x, int64_t B, int64_t T, int64_t C, const int32_t* valid_rows, void* stream);
 int dyn_col2im_1d(const float* dA, float* dx, int64_t B, int64_t Tin, int64_t Tout, int64_t C, int64_t kw, int64_t stride,
                   void* stream);
 int dyn_group_pack(const float* x, float* xg, int64_t B, int64_t T, int64_t C, int64_t G, int64_t pad, void* stream);

@@ -258,3 +258,99 @@ def test_run_wav2vec2_harness(cuda, tmp_path, capsys):
     torch.save({"encoder.weight": torch.zeros(3)}, ck)
     with pytest.raises(KeyError):
         R.main(W.apply_args(R.build_parser(), ["--mode", "su", "--seconds", "6", "-c", ck, "-nv"]))
+
+
+# ------------------------------------------------------------------------------------------------ r04: hipGraph replay over length buckets
+def test_length_aware_kernels(cuda):
+    """dyn_colnorm_fwd_len / _bwd_len, dyn_softmax_fwd_len, dyn_mask_rows: a DEVICE-side valid length gives, on the valid rows / columns, what
+    the plain kernels give on the cut tensor; the length is read when the kernel runs (updating the tensor changes the next launch)."""
+    from dynamic_asr_eval_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, T, C = 2, 300, 64
+    x = torch.randn(B, T, C, generator=g).to(cuda)
+    gamma, beta = torch.randn(C, generator=g).to(cuda), torch.randn(C, generator=g).to(cuda)
+    dy = torch.randn(B, T, C, generator=g).to(cuda)
+    valid = torch.zeros(1, dtype=torch.int32, device=cuda)
+    for n in (300, 211, 64, 1):
+        valid.fill_(n)
+        y, mean, rstd = ops.colnorm(x, gamma, beta, 1e-5, valid=valid)
+        yc, mc, rc = ops.colnorm(x[:, :n].contiguous(), gamma, beta, 1e-5)
+        assert (mean - mc).abs().max().item() < 1e-6 and ((rstd - rc).abs() / rc).max().item() < 1e-5
+        assert (y[:, :n] - yc).abs().max().item() < 1e-4 * max(1.0, yc.abs().max().item()) and torch.isfinite(y).all()
+        dyz = dy.clone(); dyz[:, n:] = 0                          # what the padded frames carry in the model's backward
+        dg, db = torch.zeros(C, device=cuda), torch.zeros(C, device=cuda)
+        dgc, dbc = torch.zeros(C, device=cuda), torch.zeros(C, device=cuda)
+        dx = ops.colnorm_bwd(x, gamma, mean, rstd, dyz, dg, db, valid=valid)
+        dxc = ops.colnorm_bwd(x[:, :n].contiguous(), gamma, mc, rc, dy[:, :n].contiguous(), dgc, dbc)
+        scale = max(1.0, dxc.abs().max().item())
+        assert (dx[:, :n] - dxc).abs().max().item() < 2e-4 * scale and dx[:, n:].abs().max().item() == 0.0 if n < T else True
+        assert (dg - dgc).abs().max().item() < 1e-3 * max(1.0, dgc.abs().max().item()) and (db - dbc).abs().max().item() < 1e-3 * max(1.0, dbc.abs().max().item())
+        s = torch.randn(3, 5, T, T, generator=g).to(cuda)
+        p = ops.softmax(s.clone(), valid=valid)
+        pc = ops.softmax(s[..., :n].contiguous())
+        assert torch.equal(p[..., :n], pc) and (n == T or p[..., n:].abs().max().item() == 0.0)      # bit for bit on the valid keys
+        m = ops.mask_rows(x.clone(), valid)
+        assert torch.equal(m[:, :n], x[:, :n]) and (n == T or m[:, n:].abs().max().item() == 0.0)
+
+
+def test_bucketed_graph_replay_matches_the_unpadded_eager_run(cuda):
+    """One captured launch sequence per length bucket (wav2vec2_model.py::forward): utterances of different lengths replay the SAME graphs with
+    their frame counts in HBM.  Against the unpadded eager run of the same model: logits of the utterance's own frames within 2e-5, every
+    parameter gradient within 1e-4 relative (same terms plus exact zeros, other summation order), also for a short utterance right after a long
+    one (stale samples zeroed), a frozen prefix, and with a byte budget that forces buckets out and back in."""
+    ref, hip = _pair(cuda, seed=11)
+    g = torch.Generator().manual_seed(12)
+    hip.graph_after, hip.bucket_frames = 1, 32
+    lengths = [9000, 10230, 6500, 9990, 3000, 10239, 6500]      # frames 27, 31, 20, 31, 9, 31, 20 -> buckets 32 (all)
+    lengths += [10560, 20000, 12000]                            # 32 -> bucket 32 (exactly full), 62 -> 64, 37 -> 64
+    def run(L, graphs, frozen=()):
+        x = (torch.randn(2, L, generator=torch.Generator().manual_seed(L)) * 0.3).to(cuda)
+        hip.use_graphs, hip.frozen = graphs, set(frozen)
+        with torch.enable_grad():
+            out = hip(x)
+        T = out.frames
+        logits = out.logits[:, :T].clone()
+        gl = torch.zeros_like(out.logits[:1])
+        gl[:, :T] = (torch.randn(1, T, logits.shape[-1], generator=torch.Generator().manual_seed(L + 1)) / T).to(cuda)   # zero past the utterance, as CTC gives
+        hip.zero_grad(); hip.backward(gl.contiguous(), n_active=1)
+        return T, logits, hip.flat_grads.clone()
+    for budget in (96 << 30, 1):                                # 1 byte: every new bucket evicts the other
+        hip.graph_budget_bytes = budget
+        if budget == 1:
+            hip.drop_graphs()
+            assert len(hip._graphs) == 0
+        for L in lengths + ([9000] if budget == 1 else []):     # ... and the first bucket comes back in at the end
+            fz = ("wav2vec2.feature_extractor",) if L == 9990 else ()
+            T, lo, gr = run(L, True, fz)
+            assert hip._ctx_static
+            T2, lo2, gr2 = run(L, False, fz)
+            assert T == T2 == hip.conv_lengths(L)[-1] and lo.shape == lo2.shape
+            assert (lo - lo2).abs().max().item() < 2e-5 * max(1.0, lo2.abs().max().item()), (L, (lo - lo2).abs().max().item())
+            assert (gr - gr2).abs().max().item() < 1e-4 * gr2.abs().max().item(), (L, (gr - gr2).abs().max().item(), gr2.abs().max().item())
+            if fz:
+                assert hip.G["wav2vec2.feature_extractor.conv_layers.0.conv.weight"].abs().max().item() == 0.0
+        assert len(hip._graphs) == (2 if budget > 1 else 1)
+    hip.use_graphs, hip.frozen = False, set()
+
+
+def test_dynamic_eval_su_with_and_without_bucket_graphs(cuda):
+    """The per-utterance loop with hipGraph replay over length buckets (default) against the same loop launched eagerly at every utterance's own
+    length (`use_graphs=False`): 9 weight-carrying utterances in 3 buckets, log-probs within 2e-4, identical argmax away from near-ties."""
+    import argparse
+    from dynamic_asr_eval_amd import wav2vec2_lib as W
+    ref, hip = _pair(cuda, seed=5)
+    tok = W.CharTokenizer()
+    g = torch.Generator().manual_seed(19)
+    ns = (4000, 7000, 12000, 5200, 23000, 9000, 11000, 21000, 3100)
+    a = [{'waveform': torch.randn(1, n, generator=g) * 0.1 + 0.01} for n in ns]
+    b = [{'waveform': u['waveform'].clone()} for u in a]
+    W.dynamic_eval_su(argparse.Namespace(epochs=1, shuffle=False), hip, a, 0, 0, tok, None, use_tqdm=False, optim=W.MADGRAD, lr_args={'lr': 1e-5})
+    assert len(hip._graphs) >= 2 and not hip.use_graphs
+    W.dynamic_eval_su(argparse.Namespace(epochs=1, shuffle=False, use_graphs=False), hip, b, 0, 0, tok, None, use_tqdm=False, optim=W.MADGRAD,
+                      lr_args={'lr': 1e-5})
+    for u, v, n in zip(a, b, ns):
+        assert u['probs'].shape == v['probs'].shape == (hip.conv_lengths(n)[-1], 32)
+        assert (u['probs'] - v['probs']).abs().max().item() < 2e-4
+        bad = u['probs'].argmax(-1) != v['probs'].argmax(-1)
+        top2 = v['probs'].topk(2, -1).values
+        assert not (bad & ((top2[:, 0] - top2[:, 1]) >= 5e-5)).any()
