@@ -21,6 +21,7 @@
 //   * XCD-aware bijective block remap: the 8 XCDs (private L2s) each walk a contiguous run of output tiles.
 //   * split-K writes fp32 slabs to a caller workspace and a second kernel sums them in slice order; the last partial
 //     round of workgroups is K-sliced the same way (tail slicing): deterministic, no float atomics.
+#include <algorithm>
 #include "common.h"
 #include <cstdlib>
 
@@ -711,12 +712,33 @@ Plan make_plan(const dyn_gemm_desc* d) {
     }
     const int64_t batch = d->nb1 * d->nb2;
     if (d->split_k == 0) {
-        for (int i = 0; i < kNumTuned; ++i) {
-            const Tuned& t = kTuned[i];
-            if (t.ta == (d->trans_a != 0) && t.tb == (d->trans_b != 0) && t.M == d->M && t.N == d->N && t.K == d->K && t.batch == batch) {
-                eval_config(d, (t.bm == 256 && !glds_eligible(d)) ? 128 : t.bm, t.bn, t.split, t.tail, &best, &cost);
-                return best;
-            }
+        // the generators write the table sorted by (ta, tb, M, N, K, batch): binary search (the wav2vec2 length buckets made it ~10x longer);
+        // a hand-edited, unsorted table is still found by the linear walk
+        auto less = [](const Tuned& a, const Tuned& b) {
+            if (a.ta != b.ta) return a.ta < b.ta;
+            if (a.tb != b.tb) return a.tb < b.tb;
+            if (a.M != b.M) return a.M < b.M;
+            if (a.N != b.N) return a.N < b.N;
+            if (a.K != b.K) return a.K < b.K;
+            return a.batch < b.batch;
+        };
+        static const bool sorted = [&] {
+            for (int i = 1; i < kNumTuned; ++i)
+                if (!less(kTuned[i - 1], kTuned[i])) return false;
+            return true;
+        }();
+        const Tuned want{d->trans_a != 0, d->trans_b != 0, d->M, d->N, d->K, batch, 0, 0, 0, 0};
+        const Tuned* hit = nullptr;
+        if (sorted) {
+            const Tuned* it = std::lower_bound(kTuned, kTuned + kNumTuned, want, less);
+            if (it != kTuned + kNumTuned && !less(want, *it)) hit = it;
+        } else {
+            for (int i = 0; i < kNumTuned && !hit; ++i)
+                if (!less(kTuned[i], want) && !less(want, kTuned[i])) hit = &kTuned[i];
+        }
+        if (hit) {
+            eval_config(d, (hit->bm == 256 && !glds_eligible(d)) ? 128 : hit->bm, hit->bn, hit->split, hit->tail, &best, &cost);
+            return best;
         }
     }
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
