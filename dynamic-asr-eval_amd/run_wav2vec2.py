@@ -67,6 +67,18 @@ def init_synthetic(model, seed=0):
         p.copy_(v.to(p.device))
 
 
+def replicate(model, n):
+    """n - 1 more replicas of `model` (same configuration and weights) for lib.dynamic_eval_su_many."""
+    out = [model]
+    for _ in range(max(0, n - 1)):
+        m = Wav2Vec2ForCTC(model.cfg, device=model.device)
+        m.flat_params.copy_(model.flat_params)
+        m.frozen = set(model.frozen)
+        m.bucket_frames, m.graph_after, m.graph_budget_bytes = model.bucket_frames, model.graph_after, model.graph_budget_bytes
+        out.append(m.eval())
+    return out
+
+
 def load_pretrained_model(args, device):
     """reference wav2vec2/lib.py:20-23 (`AutoModelForCTC.from_pretrained`) — offline: local state_dict or seeded weights."""
     model = Wav2Vec2ForCTC(None, device=device)
@@ -89,29 +101,39 @@ def main(args):
     model.eval()
     tokenizer.blank_id = 0
     decoder = GreedyCTCDecoder(tokenizer=tokenizer, blank_id=tokenizer.blank_id, device=device)
-    utterances = fetch_utterances_synthetic(args.seconds, args.seed + (0 if args.split == 'test' else 1000), stm_path=args.stm or None)
-    gold_text = normalize(" ".join(u['text'] for u in utterances)).lower()
+    # the reference's driver walks the talks of the split, one dynamic_eval call each (tedlium/run.py:139-160); offline: `--talks` synthetic talks
+    # (or the one `--stm` names).  Talks are independent (weights restored per call), so `--chains` of them can be in flight (lib.dynamic_eval_su_many)
+    n_talks = 1 if args.stm else max(1, int(getattr(args, 'talks', 1)))
+    talks = [fetch_utterances_synthetic(args.seconds, args.seed + (0 if args.split == 'test' else 1000) + 17 * t, stm_path=args.stm or None)
+             for t in range(n_talks)]
+    utterances = [u for talk in talks for u in talk]
     all_texts, all_golds = [], []
     torch.cuda.synchronize()
     t0 = time.time()
-    if args.mode == 'su':
-        utterances_out = lib.dynamic_eval_su(args, model, utterances, args.seq_len, args.overlap, tokenizer, None, use_tqdm=False,
-                                             optim=lib.MADGRAD, lr_args={'lr': args.lr})
-        for i, utt in enumerate(utterances_out):
-            utterances_out[i]['text'] = decoder(utt['probs']).lower()
-        text = ' '.join([el['text'].strip() for el in utterances_out])
-    else:
-        audio_spec = torch.cat([u['waveform'] for u in utterances], -1)                     # [1, L] waveform of the whole talk
-        logits = lib.dynamic_eval(args, model, audio_spec, args.seq_len, args.overlap, tokenizer, None, use_tqdm=False,
-                                  optim=lib.MADGRAD, lr_args={'lr': args.lr}, return_device=True)
-        text = decoder(logits).lower()
-    out = normalize(text).lower()
+    chains = max(1, min(int(getattr(args, 'chains', 1)), n_talks))
+    if args.mode == 'su' and chains > 1:
+        outs = lib.dynamic_eval_su_many(args, replicate(model, chains), talks, args.seq_len, args.overlap, tokenizer, None, optim=lib.MADGRAD,
+                                        lr_args={'lr': args.lr})
+    for t, talk in enumerate(talks):
+        gold_text = normalize(" ".join(u['text'] for u in talk)).lower()
+        if args.mode == 'su':
+            utterances_out = outs[t] if chains > 1 else lib.dynamic_eval_su(args, model, talk, args.seq_len, args.overlap, tokenizer, None, use_tqdm=False,
+                                                                            optim=lib.MADGRAD, lr_args={'lr': args.lr})
+            for i, utt in enumerate(utterances_out):
+                utterances_out[i]['text'] = decoder(utt['probs']).lower()
+            text = ' '.join([el['text'].strip() for el in utterances_out])
+        else:
+            audio_spec = torch.cat([u['waveform'] for u in talk], -1)                       # [1, L] waveform of the whole talk
+            logits = lib.dynamic_eval(args, model, audio_spec, args.seq_len, args.overlap, tokenizer, None, use_tqdm=False,
+                                      optim=lib.MADGRAD, lr_args={'lr': args.lr}, return_device=True)
+            text = decoder(logits).lower()
+        out = normalize(text).lower()
+        if args.verbose:
+            print(gold_text[:200], '\n', out[:200], '\n\n')
+        all_texts.append(out)
+        all_golds.append(gold_text)
     torch.cuda.synchronize()
     dt = time.time() - t0
-    if args.verbose:
-        print(gold_text[:200], '\n', out[:200], '\n\n')
-    all_texts.append(out)
-    all_golds.append(gold_text)
     wer, words, ins_rate, del_rate, sub_rate = word_error_rate_detail(hypotheses=all_texts, references=all_golds)
     print(f'WER: {wer}')
     if args.log != '':
@@ -129,6 +151,8 @@ def build_parser():
     ap.add_argument('--lr', type=float, default=1e-6)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--stm', type=str, default='', help='TEDLIUM .stm file: its segments define the utterances (reference tedlium/run.py:56-83)')
+    ap.add_argument('--talks', type=int, default=1, help='synthetic talks of --seconds each (the reference walks the talks of the split)')
+    ap.add_argument('--chains', type=int, default=1, help='talks in flight on the GPU (mode su): one model replica + HIP stream each')
     return ap
 
 

@@ -92,9 +92,12 @@ def _snapshot(model):
     return model.flat_params.clone()
 
 
-def dynamic_eval_ctc_loss_su(args, model, utterances, seq_len, overlap, tokenizer, processor, use_tqdm=True, optim=MADGRAD,
-                             num_negatives=1, lr_args={'lr': 1e-15}, ngram_decoder=None):
-    """reference wav2vec2/lib.py:293-462"""
+def _su_gen(args, model, utterances, seq_len, overlap, tokenizer, processor, optim=MADGRAD, num_negatives=1, lr_args={'lr': 1e-15},
+            ngram_decoder=None, use_tqdm=False):
+    """Generator form of dynamic_eval_ctc_loss_su (reference wav2vec2/lib.py:293-462): yields where the host would otherwise block on the GPU
+    (the pseudo-label ids of every utterance, the log-probs at the end), so that dynamic_eval_su_many can keep several recordings in flight
+    from one host thread.  Nothing in the loop blocks the host except those two waits: the waveforms go up in ONE pinned transfer, the label
+    ids come down and go up through pinned buffers, the utterances' log-probs collect in one pinned arena."""
     if ngram_decoder is not None:
         raise NotImplementedError("n-gram (pyctcdecode) pseudo-labels need the un-vendored decoder and its ARPA file")
     device = model.device
@@ -102,29 +105,55 @@ def dynamic_eval_ctc_loss_su(args, model, utterances, seq_len, overlap, tokenize
     original = _snapshot(model)
     blank = tokenizer.blank_id
     optimizer = optim(model.parameters(), **lr_args)
-    decoder = GreedyCTCDecoder(tokenizer=tokenizer, blank_id=blank, device=device)
     assert overlap / downsampling_factor == overlap // downsampling_factor, 'Overlap must be a multiple of the downsampling factor'
     model = disable_dropout(model)
     # hipGraph replay over utterance-length buckets (wav2vec2_model.py::forward): `args.use_graphs` (default on), `args.bucket_frames`
     was_graphs = model.use_graphs
     model.use_graphs = bool(args.__dict__.get('use_graphs', True))
     model.bucket_frames = int(args.__dict__.get('bucket_frames', model.bucket_frames))
+    lens = [int(u['waveform'].shape[-1]) for u in utterances]
+    offs, total = [], 0
+    for L in lens:
+        offs.append(total)
+        total += (L + 3) // 4 * 4                                                                # 16-byte aligned rows
+    host = torch.empty(max(total, 4), dtype=torch.float32, pin_memory=True)
+    for u, o, L in zip(utterances, offs, lens):
+        host[o:o + L] = u['waveform'].reshape(-1).to(torch.float32)
+    waves = host.to(device, non_blocking=True)
+    frames = [model.conv_lengths(L)[-1] for L in lens]
+    foffs = [sum(frames[:i]) for i in range(len(frames))]
+    probs_host, pinned, tgt_ring, tgt_turn = None, None, None, 0
     for epoch in range(args.__dict__.get('epochs', 1)):
         indexes = list(range(len(utterances)))
         indexes = random.sample(indexes, len(indexes)) if args.__dict__.get('shuffle', False) else indexes
         pbar = tqdm(indexes) if use_tqdm else indexes
         for idx in pbar:
-            wav = utterances[idx]['waveform'].to(device=device, dtype=torch.float32)            # [1, L]
-            audio_chunk = wav.reshape(1, -1).repeat(num_negatives + 1, 1).contiguous()          # [B, L]
+            L = lens[idx]
+            audio_chunk = waves[offs[idx]:offs[idx] + L].view(1, L).repeat(num_negatives + 1, 1)     # [B, L]; the copies stay clean (lib.py:391-412)
             input_values = normalize_waveform(audio_chunk)
             with torch.enable_grad():
                 out = model(input_values)
             log_p = ops.log_softmax(out.logits)                                                  # F.log_softmax, lib.py:417
             N = out.frames                      # < log_p.shape[1] when the utterance ran zero-padded in its length bucket: the frames past N are not its own
-            pseudo_targets = decoder(log_p[-1, :N])
+            ids_dev, n_dev = ops.ctc_greedy(log_p[-1, :N], blank)                                # decoder(log_p[-1]), lib.py:419: only the ids cross PCIe
+            if pinned is None or pinned[0].shape[1] < ids_dev.shape[1]:
+                pinned = (torch.empty(1, 2 * ids_dev.shape[1], dtype=torch.int32, pin_memory=True), torch.empty(1, dtype=torch.int32, pin_memory=True))
+            pinned[0][:, :ids_dev.shape[1]].copy_(ids_dev, non_blocking=True)
+            pinned[1].copy_(n_dev, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record()
+            yield                                                                                # another recording may use the host meanwhile
+            ready.synchronize()
+            pseudo_targets = tokenizer.decode(pinned[0][0, :int(pinned[1][0])].tolist())
             ids = tokenizer(pseudo_targets).input_ids
             S = len(ids)
-            targets = torch.tensor([ids if S else [0]] * num_negatives, dtype=torch.int32, device=device)
+            if tgt_ring is None or tgt_ring[0].shape[1] < max(S, 1):
+                tgt_ring = [torch.empty(num_negatives, max(2 * S, 256), dtype=torch.int32, pin_memory=True) for _ in range(4)]
+            slot = tgt_ring[tgt_turn % 4]                                                        # reused 4 utterances later: its upload is long done
+            tgt_turn += 1
+            slot[:, :max(S, 1)] = torch.as_tensor(ids if S else [0], dtype=torch.int32)
+            targets = torch.empty(num_negatives, max(S, 1), dtype=torch.int32, device=device)
+            targets.copy_(slot[:, :max(S, 1)], non_blocking=True)
             aug = log_p[:num_negatives].contiguous()
             B = aug.shape[0]
             ilen = torch.full((B,), N, dtype=torch.int32, device=device)                         # CTC over the utterance's own frames; zero gradient past them
@@ -135,10 +164,68 @@ def dynamic_eval_ctc_loss_su(args, model, utterances, seq_len, overlap, tokenize
             ops.clip_grad_norm(model.flat_grads, 10.0)                                           # lib.py:442
             optimizer.step()
             optimizer.zero_grad()
-            utterances[idx]['probs'] = log_p[-1, :N].detach().cpu()
+            if probs_host is None:
+                probs_host = torch.empty(max(sum(frames), 1), log_p.shape[-1], dtype=torch.float32, pin_memory=True)
+            probs_host[foffs[idx]:foffs[idx] + N].copy_(log_p[-1, :N], non_blocking=True)        # utterances[idx]['probs'], lib.py:452
     model.flat_params.copy_(original)                                                            # lib.py:459-460
     model.use_graphs = was_graphs
+    done = torch.cuda.Event()
+    done.record()
+    yield
+    done.synchronize()
+    if probs_host is not None:
+        for idx in range(len(utterances)):
+            utterances[idx]['probs'] = probs_host[foffs[idx]:foffs[idx] + frames[idx]].clone()
     return utterances
+
+
+def dynamic_eval_ctc_loss_su(args, model, utterances, seq_len, overlap, tokenizer, processor, use_tqdm=True, optim=MADGRAD,
+                             num_negatives=1, lr_args={'lr': 1e-15}, ngram_decoder=None):
+    """reference wav2vec2/lib.py:293-462 (one recording's utterances, weights carried from utterance to utterance and restored at the end)."""
+    gen = _su_gen(args, model, utterances, seq_len, overlap, tokenizer, processor, optim, num_negatives, lr_args, ngram_decoder, use_tqdm)
+    try:
+        while True:
+            next(gen)
+    except StopIteration as stop:
+        return stop.value
+
+
+def dynamic_eval_su_many(args, models, utterance_lists, seq_len, overlap, tokenizer, processor, optim=MADGRAD, num_negatives=1,
+                         lr_args={'lr': 1e-15}):
+    """Several RECORDINGS in flight on one GPU from one host thread (the `chains` of the conformer path, lib.dynamic_eval_many): the reference's
+    driver calls dynamic_eval_su once per talk and every call starts from the checkpoint's weights (wav2vec2/tedlium/run.py:155,
+    lib.py:455-460), so talks are independent.  One utterance step of wav2vec2-base is ~200 matrix products of 40 - 500 tiles each
+    (profiles/r04_kernel_stats_wav2vec2_su.csv): alone they leave most of the 256 CUs idle; the steps of other talks fill them.  Each model
+    replica in `models` owns a HIP stream and runs one talk at a time; returns the utterance lists in order."""
+    from .lib import _CHAIN_STREAMS, _new_chain_stream
+    device = models[0].device
+    key = torch.device(device).index
+    while len(_CHAIN_STREAMS.setdefault(key, [])) < len(models):
+        _CHAIN_STREAMS[key].append(_new_chain_stream(device, len(_CHAIN_STREAMS[key])))
+    streams = _CHAIN_STREAMS[key][:len(models)]
+    main = torch.cuda.current_stream(device)
+    for st in streams:
+        st.wait_stream(main)
+    pending = list(enumerate(utterance_lists))
+    results = [None] * len(utterance_lists)
+    free, active = list(range(len(models)))[::-1], []
+    while pending or active:
+        while pending and free:
+            ci = free.pop()
+            idx, utts = pending.pop(0)
+            active.append([_su_gen(args, models[ci], utts, seq_len, overlap, tokenizer, processor, optim, num_negatives, lr_args), ci, idx])
+        for item in list(active):
+            gen, ci, idx = item
+            with torch.cuda.stream(streams[ci]):
+                try:
+                    next(gen)
+                except StopIteration as stop:
+                    results[idx] = stop.value
+                    active.remove(item)
+                    free.append(ci)
+    for st in streams:
+        main.wait_stream(st)
+    return results
 
 
 def dynamic_eval_ctc_loss(args, model, spec, seq_len, overlap, tokenizer, processor, use_tqdm=True, optim=MADGRAD, num_negatives=1,

@@ -288,7 +288,9 @@ class Wav2Vec2ForCTC:
         if L < ent["len"]:
             ent["in"][:, L:ent["len"]].zero_()
         ent["len"] = L                                   # (beyond the previous utterance's end the buffer is still zero)
-        self._valid.copy_(torch.tensor(self.conv_lengths(L), dtype=torch.int32))
+        cl = self.conv_lengths(L)
+        self._valid[0:1].fill_(cl[0])                    # (fills, not a pageable upload: that would block the host on this stream and stall the
+        self._valid[-1:].fill_(cl[-1])                   #  other chains of wav2vec2_lib.dynamic_eval_su_many)
         ent["graph"].replay()
         self._ctx, self._ctx_static, self._ctx_key = ent["ctx"], True, key
         return SimpleNamespace(logits=ent["out"], frames=T)

@@ -354,3 +354,32 @@ def test_dynamic_eval_su_with_and_without_bucket_graphs(cuda):
         bad = u['probs'].argmax(-1) != v['probs'].argmax(-1)
         top2 = v['probs'].topk(2, -1).values
         assert not (bad & ((top2[:, 0] - top2[:, 1]) >= 5e-5)).any()
+
+
+def test_dynamic_eval_su_many_matches_one_talk_at_a_time(cuda):
+    """wav2vec2_lib.dynamic_eval_su_many (talks in flight on their own streams and model replicas, one host thread) against dynamic_eval_su on every
+    talk alone: with every utterance on the bucketed graph path (graph_after = 1) both run the same launch sequences — bit-identical log-probs;
+    every replica's weights restored; a talk with no utterances and more talks than replicas."""
+    import argparse
+    from dynamic_asr_eval_amd import run_wav2vec2 as RW, wav2vec2_lib as W
+    ref, hip = _pair(cuda, seed=5)
+    hip.graph_after = 1
+    tok = W.CharTokenizer()
+    g = torch.Generator().manual_seed(23)
+    sizes = [(4000, 7000, 12000, 5200), (9000, 3100, 23000), (), (6100, 6100, 15000, 4400, 8000)]
+    talks = [[{'waveform': torch.randn(1, n, generator=g) * 0.1 + 0.01} for n in ns] for ns in sizes]
+    args = argparse.Namespace(epochs=1, shuffle=False)
+    want = [W.dynamic_eval_su(args, hip, [dict(u) for u in t], 0, 0, tok, None, use_tqdm=False, optim=W.MADGRAD, lr_args={'lr': 1e-5}) for t in talks]
+    models = RW.replicate(hip, 2)
+    assert models[1].graph_after == 1
+    before = [m.flat_params.clone() for m in models]
+    got = W.dynamic_eval_su_many(args, models, [[dict(u) for u in t] for t in talks], 0, 0, tok, None, optim=W.MADGRAD, lr_args={'lr': 1e-5})
+    assert all(torch.equal(m.flat_params, b) for m, b in zip(models, before))
+    assert len(got) == len(talks)
+    for tw, tg, ns in zip(want, got, sizes):
+        assert len(tw) == len(tg) == len(ns)
+        for u, v in zip(tw, tg):
+            assert u['probs'].shape == v['probs'].shape and torch.equal(u['probs'], v['probs']), (u['probs'] - v['probs']).abs().max().item()
+    # the harness: 3 synthetic talks, 2 in flight
+    a = W.apply_args(RW.build_parser(), ["--mode", "su", "--seconds", "12", "--talks", "3", "--chains", "2", "-nv"])
+    assert isinstance(RW.main(a), float)
