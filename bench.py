@@ -383,8 +383,9 @@ def other_workloads(a, model, dev, which=('awmc', 'wav2vec2_su', 'enc_dec_teache
         dt_one = best_of_two(su)                                        # one talk at a time, bucket graphs replaying
         n_buckets, held = len(wm._graphs), wm.graph_bytes()
         # talks are independent (weights restored per call, wav2vec2/lib.py:455-460): two in flight, one model replica + stream each
-        wm.graph_after, wm.graph_budget_bytes = 1, 40 << 30
-        chain_models = RW.replicate(wm, 2)
+        n_chains = int(os.environ.get("DYN_W2V_CHAINS", "2"))
+        wm.graph_after = 1
+        chain_models = RW.replicate(wm, n_chains)
         margs = argparse.Namespace(epochs=1, shuffle=False)
 
         def many():
@@ -404,7 +405,7 @@ def other_workloads(a, model, dev, which=('awmc', 'wav2vec2_su', 'enc_dec_teache
         tf = (pr["flops"] + pr["attn_flops"]) * (audio_all / audio_s) / dt / 1e12
         out["wav2vec2_su"] = {"value": round(audio_all / dt, 1), "unit": "audio-s/s", "value_one_talk": round(audio_s / dt_one, 1),
                               "value_eager": round(audio_s / dt_eager, 1),
-                              "sample": f"wav2vec2-base shape; `value`: {len(talks)} talks ({sum(len(t) for t in talks)} utterances, {audio_all:.0f} s of 16 kHz audio), 2 in "
+                              "sample": f"wav2vec2-base shape; `value`: {len(talks)} talks ({sum(len(t) for t in talks)} utterances, {audio_all:.0f} s of 16 kHz audio), {n_chains} in "
                                         f"flight (one replica + stream each), hipGraph replay over length buckets of {wm.bucket_frames} frames, all captured before "
                                         f"the timed pass; `value_one_talk`: one talk ({len(utts)} utterances, {audio_s:.0f} s) at a time, {n_buckets} buckets "
                                         f"({held / 2 ** 30:.1f} GiB held); `value_eager`: the same launched kernel by kernel at every utterance's own length",

@@ -48,6 +48,9 @@ def _conv_to_hf(w):       # native [Cout, k, Cin] -> HF [Cout, Cin, k]
     return w.permute(0, 2, 1).contiguous()
 
 
+_RELEASED = object()      # Wav2Vec2ForCTC._ctx after a bucket replay whose saved activations are owned by its graphs only
+
+
 class Wav2Vec2ForCTC:
     def __init__(self, config=None, device="cuda:0"):
         self.cfg = make_config(config)
@@ -118,8 +121,9 @@ class Wav2Vec2ForCTC:
         self.use_graphs = False
         self.bucket_frames = 32                  # an utterance of T' frames runs in the bucket of ceil(T' / 32) * 32 frames (0.64 s of audio)
         self.graph_after = 2                     # a bucket is captured the n-th time it is seen; before that the utterance runs unpadded, eagerly
-        self.graph_budget_bytes = 96 << 30       # device memory the buckets' graphs (saved activations + temporaries) may hold; least recently used go first
-        self._graphs = OrderedDict()             # bucket key -> {"graph", "in", "out", "ctx", "pool", "bwd": {...}, "bytes"}
+        self.graph_budget_bytes = 64 << 30       # device memory the buckets' graphs may hold (their shared pool + static buffers); beyond it all are dropped
+        self._graphs = OrderedDict()             # bucket key -> {"graph", "in", "out", "ctx", "bwd": {...}, "bytes"}
+        self._pool = None                        # ONE private memory pool for all buckets of this model (see _forward_bucketed)
         self._seen = {}
         self._valid = None                       # device int32 [n_conv]: valid frames after every conv layer of the utterance in flight
         self._vl = None                          # = self._valid while a bucketed launch sequence is being issued / captured, else None
@@ -238,22 +242,17 @@ class Wav2Vec2ForCTC:
         return sum(e["bytes"] for e in self._graphs.values())
 
     def drop_graphs(self):
-        """Forget every captured bucket (frees their activations)."""
-        budget, self.graph_budget_bytes = self.graph_budget_bytes, -1
-        self._evict()
-        self.graph_budget_bytes = budget
-
-    def _evict(self, keep=None):
-        """Drop least-recently-used buckets until the budget holds (never inside a capture: destroying a graph there aborts the process)."""
-        while self._graphs and self.graph_bytes() > self.graph_budget_bytes:
-            key = next(iter(self._graphs))
-            if key == keep:
-                break
-            torch.cuda.synchronize(self.device)             # no replay of the bucket may still be in flight when its graphs are destroyed
-            ent = self._graphs.pop(key)
-            if self._ctx is ent["ctx"]:
-                self._ctx, self._ctx_static = None, False
+        """Forget every captured bucket (never inside a capture: destroying a graph there aborts the process).  The shared pool goes back to the
+        allocator once its last graph is gone."""
+        if self._graphs:
+            torch.cuda.synchronize(self.device)             # no replay may still be in flight when its graph is destroyed
+        for ent in self._graphs.values():
             ent.clear()
+        self._graphs.clear()
+        self._pool = None
+        if self._ctx is _RELEASED:
+            self._ctx = None
+        self._ctx_static = False
 
     def _forward_bucketed(self, x):
         B, L = x.shape
@@ -268,19 +267,26 @@ class Wav2Vec2ForCTC:
             if n < self.graph_after:
                 self._vl, self._ctx_static = None, False
                 return self._forward_eager(x)
-            self._evict()
+            if self.graph_bytes() > self.graph_budget_bytes:
+                self.drop_graphs()
+            # ONE private pool for every bucket of this model, and no Python reference to a bucket's saved activations once its backward graph
+            # exists (_backward_graphed): the next bucket's capture then reuses that memory, so the pool grows to the LARGEST bucket's needs,
+            # not to their sum (15 buckets of one 5-min talk held 26 GiB with a pool each).  Safe because the graphs of one model replay
+            # strictly as forward(b), backward(b) pairs on one stream: a bucket's activations only have to survive from its forward replay to
+            # its own backward replay, and no other graph of this model runs in between.  (Not the interleaved case of model.py::_graph_pool.)
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
             r0 = torch.cuda.memory_reserved(self.device)
             static_in = torch.zeros(B, Lb, device=self.device, dtype=torch.float32)
-            pool = torch.cuda.graph_pool_handle()       # one pool per bucket: its forward and backward alternate strictly (model.py::_graph_pool)
             graph = torch.cuda.CUDAGraph()
             prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
             self._vl = self._valid
             try:
-                with _no_gc(), torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"), _capture_guard():
+                with _no_gc(), torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"), _capture_guard():
                     out = self._forward_eager(static_in)
             finally:
                 ops.GEMM_PROFILE, self._vl = prof, None
-            ent = {"graph": graph, "in": static_in, "out": out.logits, "ctx": self._ctx, "pool": pool, "bwd": {}, "len": 0,
+            ent = {"graph": graph, "in": static_in, "out": out.logits, "ctx": self._ctx, "bwd": {}, "len": 0,
                    "bytes": max(0, torch.cuda.memory_reserved(self.device) - r0)}
             self._graphs[key] = ent
         self._graphs.move_to_end(key)
@@ -292,7 +298,7 @@ class Wav2Vec2ForCTC:
         self._valid[0:1].fill_(cl[0])                    # (fills, not a pageable upload: that would block the host on this stream and stall the
         self._valid[-1:].fill_(cl[-1])                   #  other chains of wav2vec2_lib.dynamic_eval_su_many)
         ent["graph"].replay()
-        self._ctx, self._ctx_static, self._ctx_key = ent["ctx"], True, key
+        self._ctx, self._ctx_static, self._ctx_key = (ent["ctx"] if ent["ctx"] is not None else _RELEASED), True, key
         return SimpleNamespace(logits=ent["out"], frames=T)
 
     def _forward_eager(self, x):
@@ -418,18 +424,31 @@ class Wav2Vec2ForCTC:
         ent = self._graphs[self._ctx_key]
         key = (tuple(grad_logits.shape), n_active, frozenset(self.frozen), self.grouped_wgrad)
         b = ent["bwd"].get(key)
+        if b is None and ent["ctx"] is None:
+            # another backward variant (other frozen set / active copies) after the bucket's activations were released: recompute them eagerly from
+            # the bucket's input buffer (the utterance and its frame counts are still there) and run this backward eagerly
+            self._vl = self._valid
+            try:
+                with torch.enable_grad():
+                    self._forward_eager(ent["in"])
+            finally:
+                self._vl = None
+            self._ctx_static = False
+            return self._backward_eager(grad_logits, n_active)
         if b is None:
+            self._ctx = ent["ctx"]
             r0 = torch.cuda.memory_reserved(self.device)
             static_g = grad_logits.contiguous().clone()
             graph = torch.cuda.CUDAGraph()
             prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
             try:
-                with _no_gc(), torch.cuda.graph(graph, pool=ent["pool"], capture_error_mode="thread_local"), _capture_guard():
+                with _no_gc(), torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"), _capture_guard():
                     self._backward_eager(static_g, n_active)
             finally:
                 ops.GEMM_PROFILE = prof
             b = ent["bwd"][key] = {"graph": graph, "g": static_g}
             ent["bytes"] += max(0, torch.cuda.memory_reserved(self.device) - r0)
+            ent["ctx"] = None                                    # released: both graphs hold the addresses, nobody needs the tensors
         b["g"].copy_(grad_logits)
         b["graph"].replay()
         self._ctx = None
@@ -453,8 +472,8 @@ class Wav2Vec2ForCTC:
 
     def _backward_layers(self, grad_logits, n_active=None):
         ctx = self._ctx
-        if ctx is None:
-            raise ops.DynError("backward() without a grad-mode forward")
+        if ctx is None or ctx is _RELEASED:
+            raise ops.DynError("backward() without a grad-mode forward (or use_graphs switched off between a bucketed forward and its backward)")
         if self._ctx_static:                        # a graph-owned context must survive the backward (entries are dropped below as they are used)
             ctx = dict(ctx)
             ctx["layers"], ctx["conv"] = list(ctx["layers"]), list(ctx["conv"])

@@ -297,7 +297,8 @@ def test_bucketed_graph_replay_matches_the_unpadded_eager_run(cuda):
     """One captured launch sequence per length bucket (wav2vec2_model.py::forward): utterances of different lengths replay the SAME graphs with
     their frame counts in HBM.  Against the unpadded eager run of the same model: logits of the utterance's own frames within 2e-5, every
     parameter gradient within 1e-4 relative (same terms plus exact zeros, other summation order), also for a short utterance right after a long
-    one (stale samples zeroed), a frozen prefix, and with a byte budget that forces buckets out and back in."""
+    one (stale samples zeroed), a frozen prefix (another backward variant after the bucket's activations were released: recomputed eagerly), and
+    with a byte budget that forces the buckets out and back in.  All buckets of a model share one memory pool."""
     ref, hip = _pair(cuda, seed=11)
     g = torch.Generator().manual_seed(12)
     hip.graph_after, hip.bucket_frames = 1, 32
@@ -308,13 +309,14 @@ def test_bucketed_graph_replay_matches_the_unpadded_eager_run(cuda):
         hip.use_graphs, hip.frozen = graphs, set(frozen)
         with torch.enable_grad():
             out = hip(x)
+        assert hip._ctx_static == graphs
         T = out.frames
         logits = out.logits[:, :T].clone()
         gl = torch.zeros_like(out.logits[:1])
         gl[:, :T] = (torch.randn(1, T, logits.shape[-1], generator=torch.Generator().manual_seed(L + 1)) / T).to(cuda)   # zero past the utterance, as CTC gives
         hip.zero_grad(); hip.backward(gl.contiguous(), n_active=1)
         return T, logits, hip.flat_grads.clone()
-    for budget in (96 << 30, 1):                                # 1 byte: every new bucket evicts the other
+    for budget in (96 << 30, 1):                                # 1 byte: every new bucket drops the others
         hip.graph_budget_bytes = budget
         if budget == 1:
             hip.drop_graphs()
@@ -322,7 +324,6 @@ def test_bucketed_graph_replay_matches_the_unpadded_eager_run(cuda):
         for L in lengths + ([9000] if budget == 1 else []):     # ... and the first bucket comes back in at the end
             fz = ("wav2vec2.feature_extractor",) if L == 9990 else ()
             T, lo, gr = run(L, True, fz)
-            assert hip._ctx_static
             T2, lo2, gr2 = run(L, False, fz)
             assert T == T2 == hip.conv_lengths(L)[-1] and lo.shape == lo2.shape
             assert (lo - lo2).abs().max().item() < 2e-5 * max(1.0, lo2.abs().max().item()), (L, (lo - lo2).abs().max().item())
