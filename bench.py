@@ -36,7 +36,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=8)      # two lockstep groups of 4: one per chain, no partial group
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=3600.0, help="length of each synthetic recording")
     ap.add_argument("--seq_len", type=int, default=16384)
@@ -523,6 +523,14 @@ def main():
         t_end = time.perf_counter() + a.prewarm_s
         while time.perf_counter() < t_end:
             run_many(specs[:1] * (n_chains * R))
+        rem = a.steps % R if R > 1 else 0
+        if rem and a.graphs:
+            # K is not a multiple of the group size: the timed region ends with a PARTIAL group, whose replica range has graphs of its own
+            # (model.py::_graph_pool) on whichever chain takes it — captured here (seen twice), not inside the timed region
+            for _ in range(2):
+                if n_chains > 1:
+                    run_many(specs[:1] * (R + rem))       # a full group on chain 0, the partial one on chain 1
+                run_many(specs[:1] * rem)                 # the partial one on chain 0
     if a.warmup:
         run_many(specs[:a.warmup])              # W untimed steps (every chain's stream and workspace was already warmed by the prewarm)
     ddist.barrier()
