@@ -486,14 +486,15 @@ def main():
 
     decoder = GreedyCTCDecoder(tok, blank_id=a.vocab, device=dev)
 
-    def run_many(spec_list, tokenizer=None, pcie=None, online=None):
+    def run_many(spec_list, tokenizer=None, pcie=None, online=None, group_sizes=None):
         """`n_chains` recordings in flight: one stream + one model replica each, advanced round-robin by one host thread."""
         pcie = a.pcie if pcie is None else pcie
         run_args = args
         if online is not None and bool(online) != bool(a.online):
             run_args = argparse.Namespace(**vars(args)); run_args.online = bool(online)
-        outs = lib.dynamic_eval_many(run_args, models[:max(1, min(len(models), (len(spec_list) + R - 1) // R))], spec_list, a.seq_len, a.overlap, tokenizer or tok,
-                                     use_tqdm=False, return_device=not pcie)
+        n_groups = len(group_sizes) if group_sizes and R > 1 else len(lib.lockstep_group_sizes(len(spec_list), R, len(models)))
+        outs = lib.dynamic_eval_many(run_args, models[:max(1, min(len(models), n_groups))], spec_list, a.seq_len, a.overlap, tokenizer or tok,
+                                     use_tqdm=False, return_device=not pcie, **({"group_sizes": group_sizes} if group_sizes and R > 1 else {}))
         if pcie:   # the reference's contract: np.float32 [T_ds, V+1] back on the host (lib.py:640), decoded from there
             return [decoder.ids(torch.from_numpy(o).to(dev)) for o in outs]
         return [decoder.ids(o) for o in outs]
@@ -523,14 +524,12 @@ def main():
         t_end = time.perf_counter() + a.prewarm_s
         while time.perf_counter() < t_end:
             run_many(specs[:1] * (n_chains * R))
-        rem = a.steps % R if R > 1 else 0
-        if rem and a.graphs:
-            # K is not a multiple of the group size: the timed region ends with a PARTIAL group, whose replica range has graphs of its own
-            # (model.py::_graph_pool) on whichever chain takes it — captured here (seen twice), not inside the timed region
-            for _ in range(2):
-                if n_chains > 1:
-                    run_many(specs[:1] * (R + rem))       # a full group on chain 0, the partial one on chain 1
-                run_many(specs[:1] * rem)                 # the partial one on chain 0
+        if R > 1 and a.graphs:
+            # lib.lockstep_group_sizes may cut the K recordings into groups SMALLER than R (20 on 2 chains: 4 4 3 3 3 3); a partial group's replica
+            # range has graphs of its own (model.py::_graph_pool), captured the second time it is seen — here, on every chain, not inside the timed region
+            for n in sorted({sz for sz in lib.lockstep_group_sizes(a.steps, R, n_chains) if sz != R}, reverse=True):
+                for _ in range(2):
+                    run_many(specs[:1] * (n * n_chains), group_sizes=[n] * n_chains)
     if a.warmup:
         run_many(specs[:a.warmup])              # W untimed steps (every chain's stream and workspace was already warmed by the prewarm)
     ddist.barrier()

@@ -429,3 +429,18 @@ int main() {
     subprocess.run(["g++", "-O2", "-std=c++17", str(src), "-o", str(exe), "-lm"], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_lockstep_group_sizes_balance_the_chains():
+    """lib.lockstep_group_sizes: every recording in exactly one group, no group above R, and with several chains the group count is a multiple of
+    the chain count (sizes within one of each other) so that the chains finish together."""
+    from dynamic_asr_eval_amd.lib import lockstep_group_sizes as g
+    assert g(20, 4, 2) == [4, 4, 3, 3, 3, 3] and g(8, 4, 2) == [4, 4] and g(6, 4, 2) == [3, 3] and g(4, 4, 2) == [4] and g(0, 4, 2) == []
+    assert g(7, 3, 1) == [3, 2, 2] and g(5, 1, 3) == [1] * 5 and g(2, 4, 3) == [2]
+    for n in range(1, 60):
+        for R in (1, 2, 3, 4, 6):
+            for c in (1, 2, 3, 4):
+                s = g(n, R, c)
+                assert sum(s) == n and max(s) <= R and min(s) >= 1 and max(s) - min(s) <= 1 and s == sorted(s, reverse=True)
+                if c > 1 and len(s) > 1 and n >= c * 2:
+                    assert len(s) % c == 0 or len(s) == n, (n, R, c, s)
