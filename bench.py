@@ -33,6 +33,13 @@ import torch  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 256 CUs x 2.4 GHz
 
 
+def progress(msg):
+    """Stage marker on STDERR (stdout carries exactly one JSON line): a 20-step run is silent for 7 - 8 minutes otherwise, which a watchdog on
+    the GPU box takes for a hang."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -520,6 +527,7 @@ def main():
         model.load_state_dict(model.state_dict())   # the calibrated blank bias into every replica
     for m in models[1:]:                       # every chain starts from the same weights
         m.flat_params.copy_(model.flat_params)
+    progress("models built, calibrated; prewarm")
     if a.prewarm_s > 0:     # untimed, before the W warm-up steps: the workload itself, until the GPU has been under load for prewarm_s
         t_end = time.perf_counter() + a.prewarm_s
         while time.perf_counter() < t_end:
@@ -530,6 +538,8 @@ def main():
             for n in sorted({sz for sz in lib.lockstep_group_sizes(a.steps, R, n_chains) if sz != R}, reverse=True):
                 for _ in range(2):
                     run_many(specs[:1] * (n * n_chains), group_sizes=[n] * n_chains)
+                    progress(f"prewarmed groups of {n}")
+    progress("warm-up steps")
     if a.warmup:
         run_many(specs[:a.warmup])              # W untimed steps (every chain's stream and workspace was already warmed by the prewarm)
     ddist.barrier()
@@ -540,11 +550,13 @@ def main():
     # "exclusive" (the device is drained around the step: the kernel's own duration, what rocprofv3 --chains 1 averages).
     WEVERY = max(2, a.sample_every)
     ops.gemm_profile_start(every=4, window_every=WEVERY if a.graphs else 0)
+    progress(f"timed region: {a.steps} steps")
     t0 = time.perf_counter()
     hyps = run_many(specs[a.warmup:a.warmup + a.steps])
     torch.cuda.synchronize(dev)
     ddist.barrier()
     dt = time.perf_counter() - t0
+    progress(f"timed region done in {dt:.1f} s; side measurements")
     prof = ops.gemm_profile_stop()
     if os.environ.get("DYN_DEBUG_HOST"):
         print(f"[host] wall {dt:.3f} s, blocked on pseudo-label ids {lib.HOST_WAIT[0]:.3f} s (incl. warm-up)", file=sys.stderr)
@@ -559,8 +571,10 @@ def main():
         sl = specs[a.warmup:a.warmup + min(n_side, a.steps)]
         if a.label_tokens > 0:
             side["value_degenerate_labels"] = round(a.seconds * len(sl) / timed(sl, tokenizer=plain_tok), 3)
+            progress("side: degenerate labels done")
         if not a.pcie:
             side["value_boundary"] = round(a.seconds * len(sl) / timed(sl, pcie=1), 3)
+            progress("side: boundary done")
         if not a.online:   # the mode of the reference's only published timing (`online=True`: no final pass, timeit_earnings22.sh:1)
             side["value_online"] = round(a.seconds * len(sl) / timed(sl, online=1), 3)
         side["side_sample"] = f"{len(sl)} recordings each, same chains, after the timed region"
@@ -614,8 +628,10 @@ def main():
             side_model = SCConformerXL(vocab_size=a.vocab, device=dev)
             side_model.load_state_dict(model.state_dict())
         if world == 1 and a.side_workloads:
+            progress("side: online done; other workloads")
             out["other_workloads"] = other_workloads(a, side_model, dev)
         if world == 1 and not a.no_cpu_baseline:
+            progress("cpu baseline + parity")
             for m in models + [side_model]:                            # the parity leg runs on the bench's own (restored) weights
                 m.use_graphs = bool(a.graphs)
             out["cpu_baseline"], out["parity"] = cpu_baseline(a, model, dev)       # parity through the path that was timed (the group model when R > 1)
