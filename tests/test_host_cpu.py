@@ -444,3 +444,23 @@ def test_lockstep_group_sizes_balance_the_chains():
                 assert sum(s) == n and max(s) <= R and min(s) >= 1 and max(s) - min(s) <= 1 and s == sorted(s, reverse=True)
                 if c > 1 and len(s) > 1 and n >= c * 2:
                     assert len(s) % c == 0 or len(s) == n, (n, R, c, s)
+
+
+def test_wav2vec2_length_buckets_host_arithmetic():
+    """wav2vec2_model.Wav2Vec2ForCTC.conv_lengths / samples_for_frames / _bucket (host side of the hipGraph length buckets): the bucket's sample
+    count holds every utterance that has at most the bucket's frames, the bucket itself has exactly its frame count at every conv layer the
+    static shapes are built from, and samples_for_frames is the smallest such length."""
+    from types import SimpleNamespace
+    from dynamic_asr_eval_amd.wav2vec2_model import DEFAULT_CONFIG, Wav2Vec2ForCTC as W
+    me = SimpleNamespace(cfg=dict(DEFAULT_CONFIG), bucket_frames=32)
+    me.conv_lengths = lambda L: W.conv_lengths(me, L)
+    me.samples_for_frames = lambda T: W.samples_for_frames(me, T)
+    assert me.samples_for_frames(1) == 400 and me.conv_lengths(400)[-1] == 1 and me.conv_lengths(16000)[-1] == 49       # HF: 49 frames per second
+    for T in (1, 2, 31, 32, 33, 448, 1600):
+        L = me.samples_for_frames(T)
+        assert me.conv_lengths(L)[-1] == T and me.conv_lengths(L - 1)[-1] == T - 1
+    for L in list(range(400, 2400, 7)) + [10239, 10240, 10559, 10560, 10561, 131072, 480000, 480319]:
+        T, Tb, Lb = W._bucket(me, L)
+        assert T == me.conv_lengths(L)[-1] and Tb % 32 == 0 and Tb - 32 < T <= Tb and Lb >= L
+        assert me.conv_lengths(Lb)[-1] == Tb and me.conv_lengths(Lb + 1)[-1] == Tb + 1
+        assert all(v <= b for v, b in zip(me.conv_lengths(L), me.conv_lengths(Lb)))      # every layer's valid frames fit the static shape
