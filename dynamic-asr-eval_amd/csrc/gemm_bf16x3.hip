@@ -1,0 +1,149 @@
+// EXPERIMENTAL — not on the product path, not called by any default code path or default test ("where the next factor is").
+//
+// An fp32 GEMM on the bf16 matrix cores by OPERAND SPLITTING: every fp32 operand is exactly the sum of three bf16 terms (3 x 8 significant
+// bits), a product keeps the six terms a_i * b_j with i + j <= 2 (the dropped ones are below 2^-24 relative), each bf16 x bf16 product is
+// exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, so the only roundings are fp32 accumulations: fp32-grade results
+// (scripts/probe_bf16x3_numerics.py, tests/bf16x3_parity_study.py) at six dense bf16 MFMAs per fp32 product — a ceiling of ~417 TFLOP/s
+// fp32-equivalent against 157 TFLOP/s for v_mfma_f32_32x32x2_f32.
+//
+// This file is the first, correctness-first form of that kernel, written at the end of round 4 WITHOUT a GPU run (the round's GPU budget was
+// spent): it compiles for gfx950 and its index arithmetic is checked by a lane-level emulation on the CPU (scripts/emulate_bf16x3_kernel.py),
+// but it has not executed on hardware.  Round 5 starts by running tests/test_gemm_bf16x3_gpu.py (opt-in: DYN_EXPERIMENTAL=1) and
+// scripts/probe_gemm_bf16x3.py.  Shape: C[M, N] = X[M, K] . W[N, K]^T (+ bias[N]) — the `linear` layout of the path (reference: every nn.Linear
+// inside model(audio_signal=...), lcasr/lib.py:550), both operands K-contiguous, which is also what the MFMA fragment wants: lane (r = l & 31,
+// h = l >> 5) holds X[row r][k = 8h + j] and W[col r][k = 8h + j], j = 0..7 — 8 consecutive k of one row.
+//
+// 128 x 128 tile per 256-thread workgroup, one 64 x 64 quadrant (2 x 2 MFMA tiles, 64 accumulator VGPRs) per wave, BK = 32 per LDS stage.
+// The split happens ONCE per staged element on the way into LDS (three bf16 planes per operand, row stride padded by 16 B).  No software
+// pipelining, no direct-to-LDS loads, no XCD mapping yet: those are the next steps once the numbers of this form are known.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int BM = 128, BN = 128, BK = 32, NTHREADS = 256;
+constexpr int LDK = BK + 8;   // row stride in bf16 elements: 80 B = 5 x 16 B (fragments stay 16-B aligned, rows spread over the banks)
+
+// fp32 -> nearest-even bf16 bits.  Integer form: a NaN input may come out as 0 / inf (MI355X_MICROARCH.md); operands here are finite activations
+// and weights — the production form should use the cvt instruction.
+__device__ __forceinline__ unsigned short bf16_bits(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_value(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// x = t0 + t1 + t2 exactly (each residual is exact in fp32: the subtrahend is x's leading bits)
+__device__ __forceinline__ void split3(float x, unsigned short& t0, unsigned short& t1, unsigned short& t2) {
+    t0 = bf16_bits(x);
+    const float r1 = x - bf16_value(t0);
+    t1 = bf16_bits(r1);
+    const float r2 = r1 - bf16_value(t1);
+    t2 = bf16_bits(r2);
+}
+
+// stage a [128][BK] fp32 tile (rows row0 .. row0 + 127 of a [rows][ld] matrix, columns k0 .. k0 + BK - 1) as three bf16 planes
+__device__ __forceinline__ void stage_split(const float* __restrict__ src, int64_t ld, int64_t rows, int64_t row0, int64_t k0,
+                                            unsigned short (*dst)[BM][LDK]) {
+#pragma unroll
+    for (int i = 0; i < (BM * BK / 4) / NTHREADS; ++i) {   // 1024 float4 per tile, 4 per thread
+        const int idx = threadIdx.x + i * NTHREADS;
+        const int row = idx >> 3, c4 = (idx & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + row < rows) v = *reinterpret_cast<const float4*>(src + (row0 + row) * ld + k0 + c4);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        unsigned short t[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3(e[j], t[0][j], t[1][j], t[2][j]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            uint2 w;
+            w.x = (unsigned)t[p][0] | ((unsigned)t[p][1] << 16);
+            w.y = (unsigned)t[p][2] | ((unsigned)t[p][3] << 16);
+            *reinterpret_cast<uint2*>(&dst[p][row][c4]) = w;   // 8-B aligned: c4 * 2 B is a multiple of 8, the row stride of 16
+        }
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16x3_nt_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                                  const float* __restrict__ bias, float* __restrict__ C, int64_t M,
+                                                                  int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc) {
+    __shared__ __attribute__((aligned(16))) unsigned short sX[3][BM][LDK];   // 30 720 B
+    __shared__ __attribute__((aligned(16))) unsigned short sW[3][BN][LDK];   // 30 720 B
+    const int64_t bm = (int64_t)blockIdx.y * BM, bn = (int64_t)blockIdx.x * BN;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
+
+    for (int64_t k0 = 0; k0 < K; k0 += BK) {
+        stage_split(X, ldx, M, bm, k0, sX);
+        stage_split(W, ldw, N, bn, k0, sW);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int kk = ks * 16 + 8 * h;
+            bf16x8 a[3][2], b[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[p][t] = *reinterpret_cast<const bf16x8*>(&sX[p][wm + t * 32 + r][kk]);
+                    b[p][t] = *reinterpret_cast<const bf16x8*>(&sW[p][wn + t * 32 + r][kk]);
+                }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    f32x16 c = acc[mi][ni];
+                    // the three smallest terms first, the leading product last (the order of the CPU emulations)
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[2][ni], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][mi], b[0][ni], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mi], b[1][ni], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[1][ni], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mi], b[0][ni], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[0][ni], c, 0, 0, 0);
+                    acc[mi][ni] = c;
+                }
+        }
+        __syncthreads();
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int64_t col = bn + wn + ni * 32 + r;
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t row = bm + wm + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (row < M) C[row * ldc + col] = acc[mi][ni][q] + bv;
+            }
+        }
+}
+
+}  // namespace
+
+// C[M, N] = X[M, K] . W[N, K]^T (+ bias[N]) in fp32-grade arithmetic on the bf16 matrix cores (see the header of this file: EXPERIMENTAL).
+// K must be a multiple of 32; X, W 16-byte aligned with ldx, ldw multiples of 4 (float4 loads).  Operands must be finite.
+extern "C" int dyn_gemm_bf16x3_nt(const float* X, const float* W, const float* bias, float* C, int64_t M, int64_t N, int64_t K, int64_t ldx,
+                                  int64_t ldw, int64_t ldc, void* stream) {
+    DYN_REQUIRE(X && W && C && M > 0 && N > 0 && K > 0, DYN_E_ARG, "dyn_gemm_bf16x3_nt: bad arguments");
+    DYN_REQUIRE(K % BK == 0, DYN_E_UNSUPPORTED, "dyn_gemm_bf16x3_nt: K = %lld is not a multiple of %d", (long long)K, BK);
+    DYN_REQUIRE(ldx >= K && ldw >= K && ldc >= N && ldx % 4 == 0 && ldw % 4 == 0 && (((uintptr_t)X) & 15) == 0 && (((uintptr_t)W) & 15) == 0,
+                DYN_E_ARG, "dyn_gemm_bf16x3_nt: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+    const int64_t gx = dyn::cdiv(N, BN), gy = dyn::cdiv(M, BM);
+    DYN_REQUIRE(gx < 65536 * 16 && gy < 65536, DYN_E_ARG, "dyn_gemm_bf16x3_nt: grid too large");
+    hipLaunchKernelGGL(gemm_bf16x3_nt_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(NTHREADS), 0, (hipStream_t)stream, X, W, bias, C, M, N, K,
+                       ldx, ldw, ldc);
+    return dyn::check_launch("dyn_gemm_bf16x3_nt");
+}

@@ -1,0 +1,30 @@
+"""EXPERIMENTAL kernel dyn_gemm_bf16x3_nt (csrc/gemm_bf16x3.hip): fp32-grade X W^T on the bf16 matrix cores by operand
+splitting.  The kernel was written at the end of round 4 without a GPU run, so this test is OPT-IN: it runs only with DYN_EXPERIMENTAL=1 (the
+round-end suite must not depend on code that has never executed).  Bar: against float64, no further from it than twice the path's own fp32
+GEMM (dyn_gemm_f32) plus one fp32 ulp of the largest output — the emulations (scripts/probe_bf16x3_numerics.py) put it at 1.5 - 2x."""
+import os
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("DYN_EXPERIMENTAL") != "1", reason="experimental kernel: set DYN_EXPERIMENTAL=1")]
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(128, 128, 64, False), (150, 200, 96, True), (33, 129, 32, True), (4096, 768, 768, True), (2048, 3072, 768, False)])
+def test_bf16x3_product_is_fp32_grade(cuda, M, N, K, bias):
+    from dynamic_asr_eval_amd import ops
+    from dynamic_asr_eval_amd._lib import check, load
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(cuda)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(cuda)
+    b = torch.randn(N, generator=g).to(cuda) if bias else None
+    c = torch.full((M, N), float("nan"), device=cuda)
+    check(load().dyn_gemm_bf16x3_nt(x.data_ptr(), w.data_ptr(), b.data_ptr() if bias else None, c.data_ptr(), M, N, K, K, K, N,
+                                    torch.cuda.current_stream().cuda_stream), "dyn_gemm_bf16x3_nt")
+    ref = x.double() @ w.double().t() + (b.double() if bias else 0.0)
+    f32 = ops.linear(x, w, b)
+    assert torch.isfinite(c).all(), "an output element was never written"
+    scale = ref.abs().max().item()
+    e3, e1 = (c.double() - ref).abs().max().item() / scale, (f32.double() - ref).abs().max().item() / scale
+    print(f"M={M} N={N} K={K}: |bf16x3 - f64| {e3:.2e}, |dyn_gemm_f32 - f64| {e1:.2e} (relative to max |C|)")
+    assert e3 < 2 * e1 + 1.2e-7, (e3, e1)
