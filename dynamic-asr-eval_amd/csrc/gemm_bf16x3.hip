@@ -6,10 +6,10 @@
 // (scripts/probe_bf16x3_numerics.py, tests/bf16x3_parity_study.py) at six dense bf16 MFMAs per fp32 product — a ceiling of ~417 TFLOP/s
 // fp32-equivalent against 157 TFLOP/s for v_mfma_f32_32x32x2_f32.
 //
-// This file is the first, correctness-first form of that kernel, written at the end of round 4 WITHOUT a GPU run (the round's GPU budget was
-// spent): it compiles for gfx950 and its index arithmetic is checked by a lane-level emulation on the CPU (scripts/emulate_bf16x3_kernel.py),
-// but it has not executed on hardware.  Round 5 starts by running tests/test_gemm_bf16x3_gpu.py (opt-in: DYN_EXPERIMENTAL=1) and
-// scripts/probe_gemm_bf16x3.py.  Shape: C[M, N] = X[M, K] . W[N, K]^T (+ bias[N]) — the `linear` layout of the path (reference: every nn.Linear
+// This file is the first, correctness-first form of that kernel, written at the end of round 4: its index arithmetic was checked by a lane-level
+// emulation on the CPU (scripts/emulate_bf16x3_kernel.py), then it ran on the MI355X with the round's last GPU seconds
+// (tests/test_gemm_bf16x3_gpu.py: five shapes, each closer to float64 than dyn_gemm_f32; scripts/probe_gemm_bf16x3.py: 83 - 108 TFLOP/s
+// fp32-equivalent at M >= 8192 against 120 - 131 for the tuned fp32 kernel — profiles/r04_bf16x3_kernel_first_*.log).  Shape: C[M, N] = X[M, K] . W[N, K]^T (+ bias[N]) — the `linear` layout of the path (reference: every nn.Linear
 // inside model(audio_signal=...), lcasr/lib.py:550), both operands K-contiguous, which is also what the MFMA fragment wants: lane (r = l & 31,
 // h = l >> 5) holds X[row r][k = 8h + j] and W[col r][k = 8h + j], j = 0..7 — 8 consecutive k of one row.
 //
