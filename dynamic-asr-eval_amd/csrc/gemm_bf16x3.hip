@@ -1,4 +1,5 @@
-// EXPERIMENTAL — not on the product path, not called by any default code path or default test ("where the next factor is").
+// EXPERIMENTAL — not on the product path: nothing but tests/test_gemm_bf16x3_gpu.py and scripts/probe_gemm_bf16x3.py calls it (DESIGN.md section 6,
+// "where the next factor is").
 //
 // An fp32 GEMM on the bf16 matrix cores by OPERAND SPLITTING: every fp32 operand is exactly the sum of three bf16 terms (3 x 8 significant
 // bits), a product keeps the six terms a_i * b_j with i + j <= 2 (the dropped ones are below 2^-24 relative), each bf16 x bf16 product is
@@ -9,8 +10,9 @@
 // This file is the first, correctness-first form of that kernel, written at the end of round 4: its index arithmetic was checked by a lane-level
 // emulation on the CPU (scripts/emulate_bf16x3_kernel.py), then it ran on the MI355X with the round's last GPU seconds
 // (tests/test_gemm_bf16x3_gpu.py: five shapes, each closer to float64 than dyn_gemm_f32; scripts/probe_gemm_bf16x3.py: 83 - 108 TFLOP/s
-// fp32-equivalent at M >= 8192 against 120 - 131 for the tuned fp32 kernel — profiles/r04_bf16x3_kernel_first_*.log).  Shape: C[M, N] = X[M, K] . W[N, K]^T (+ bias[N]) — the `linear` layout of the path (reference: every nn.Linear
-// inside model(audio_signal=...), lcasr/lib.py:550), both operands K-contiguous, which is also what the MFMA fragment wants: lane (r = l & 31,
+// fp32-equivalent at M >= 8192 against 120 - 131 for the tuned fp32 kernel — profiles/r04_bf16x3_kernel_first_*.log).
+// Shape: C[M, N] = X[M, K] . W[N, K]^T (+ bias[N]) — the `linear` layout of the path (reference: every nn.Linear inside
+// model(audio_signal=...), lcasr/lib.py:550), both operands K-contiguous, which is also what the MFMA fragment wants: lane (r = l & 31,
 // h = l >> 5) holds X[row r][k = 8h + j] and W[col r][k = 8h + j], j = 0..7 — 8 consecutive k of one row.
 //
 // 128 x 128 tile per 256-thread workgroup, one 64 x 64 quadrant (2 x 2 MFMA tiles, 64 accumulator VGPRs) per wave, BK = 32 per LDS stage.
