@@ -18,6 +18,7 @@
 // 128 x 128 tile per 256-thread workgroup, one 64 x 64 quadrant (2 x 2 MFMA tiles, 64 accumulator VGPRs) per wave, BK = 32 per LDS stage.
 // The split happens ONCE per staged element on the way into LDS (three bf16 planes per operand, row stride padded by 16 B).  No software
 // pipelining, no direct-to-LDS loads, no XCD mapping yet: those are the next steps once the numbers of this form are known.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -68,6 +69,53 @@ __device__ __forceinline__ void stage_split(const float* __restrict__ src, int64
     }
 }
 
+// ---- variant 2 (NOT YET RUN ON HARDWARE — selected only by DYN_BF16X3_VARIANT=2): the same tile and fragment layout, but (a) the global loads of
+// tile k + 1 are issued before the MFMAs of tile k and land in registers while they run (the first form waits for every load), and (b) the split
+// uses the hardware conversion (a plain cast compiles to v_cvt_pk_bf16_f32 at -O3: round-to-nearest-even like bf16_bits on finite values, ~1/3
+// of the integer form's VALU work).
+__device__ __forceinline__ void split3_cvt(float x, unsigned short& t0, unsigned short& t1, unsigned short& t2) {
+    const __bf16 h0 = (__bf16)x;
+    const float r1 = x - (float)h0;
+    const __bf16 h1 = (__bf16)r1;
+    const float r2 = r1 - (float)h1;
+    const __bf16 h2 = (__bf16)r2;
+    t0 = __builtin_bit_cast(unsigned short, h0);
+    t1 = __builtin_bit_cast(unsigned short, h1);
+    t2 = __builtin_bit_cast(unsigned short, h2);
+}
+
+constexpr int F4_PER_THREAD = (BM * BK / 4) / NTHREADS;   // 4
+
+__device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t ld, int64_t rows, int64_t row0, int64_t k0, float4 (&v)[F4_PER_THREAD]) {
+#pragma unroll
+    for (int i = 0; i < F4_PER_THREAD; ++i) {
+        const int idx = threadIdx.x + i * NTHREADS;
+        const int row = idx >> 3, c4 = (idx & 7) * 4;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + row < rows) v[i] = *reinterpret_cast<const float4*>(src + (row0 + row) * ld + k0 + c4);
+    }
+}
+
+__device__ __forceinline__ void store_split(const float4 (&v)[F4_PER_THREAD], unsigned short (*dst)[BM][LDK]) {
+#pragma unroll
+    for (int i = 0; i < F4_PER_THREAD; ++i) {
+        const int idx = threadIdx.x + i * NTHREADS;
+        const int row = idx >> 3, c4 = (idx & 7) * 4;
+        const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        unsigned short t[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3_cvt(e[j], t[0][j], t[1][j], t[2][j]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            uint2 w;
+            w.x = (unsigned)t[p][0] | ((unsigned)t[p][1] << 16);
+            w.y = (unsigned)t[p][2] | ((unsigned)t[p][3] << 16);
+            *reinterpret_cast<uint2*>(&dst[p][row][c4]) = w;
+        }
+    }
+}
+
+template <bool PIPE>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16x3_nt_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                                   const float* __restrict__ bias, float* __restrict__ C, int64_t M,
                                                                   int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc) {
@@ -85,10 +133,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16x3_nt_kernel(const float* _
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
 
+    float4 px[F4_PER_THREAD], pw[F4_PER_THREAD];
+    if (PIPE) { load_tile(X, ldx, M, bm, 0, px); load_tile(W, ldw, N, bn, 0, pw); }
     for (int64_t k0 = 0; k0 < K; k0 += BK) {
-        stage_split(X, ldx, M, bm, k0, sX);
-        stage_split(W, ldw, N, bn, k0, sW);
-        __syncthreads();
+        if (PIPE) {
+            store_split(px, sX);
+            store_split(pw, sW);
+            __syncthreads();
+            if (k0 + BK < K) { load_tile(X, ldx, M, bm, k0 + BK, px); load_tile(W, ldw, N, bn, k0 + BK, pw); }   // in flight during the MFMAs below
+        } else {
+            stage_split(X, ldx, M, bm, k0, sX);
+            stage_split(W, ldw, N, bn, k0, sW);
+            __syncthreads();
+        }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int kk = ks * 16 + 8 * h;
@@ -145,7 +202,12 @@ extern "C" int dyn_gemm_bf16x3_nt(const float* X, const float* W, const float* b
                 DYN_E_ARG, "dyn_gemm_bf16x3_nt: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
     const int64_t gx = dyn::cdiv(N, BN), gy = dyn::cdiv(M, BM);
     DYN_REQUIRE(gx < 65536 * 16 && gy < 65536, DYN_E_ARG, "dyn_gemm_bf16x3_nt: grid too large");
-    hipLaunchKernelGGL(gemm_bf16x3_nt_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(NTHREADS), 0, (hipStream_t)stream, X, W, bias, C, M, N, K,
-                       ldx, ldw, ldc);
+    static const int variant = [] { const char* e = getenv("DYN_BF16X3_VARIANT"); return e ? atoi(e) : 1; }();
+    if (variant == 2)   // prefetching form: written after the round's last GPU run, so it has not executed yet (see the kernel's comment)
+        hipLaunchKernelGGL(gemm_bf16x3_nt_kernel<true>, dim3((unsigned)gx, (unsigned)gy), dim3(NTHREADS), 0, (hipStream_t)stream, X, W, bias, C, M,
+                           N, K, ldx, ldw, ldc);
+    else
+        hipLaunchKernelGGL(gemm_bf16x3_nt_kernel<false>, dim3((unsigned)gx, (unsigned)gy), dim3(NTHREADS), 0, (hipStream_t)stream, X, W, bias, C, M,
+                           N, K, ldx, ldw, ldc);
     return dyn::check_launch("dyn_gemm_bf16x3_nt");
 }
