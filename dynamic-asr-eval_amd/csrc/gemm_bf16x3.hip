@@ -86,36 +86,61 @@ __device__ __forceinline__ void split3_cvt(float x, unsigned short& t0, unsigned
 
 constexpr int F4_PER_THREAD = (BM * BK / 4) / NTHREADS;   // 4
 
+// KCONT: the tile's 128-dimension is the ROW index of the source and K is contiguous (X of X W^T, W stored [N][K]): float4 along K.
+// !KCONT: the source is stored [K][128-dimension] (a transposed A, or B stored [K][N]): float4 along the 128-dimension, guarded element-wise at
+// the ragged edge; the planes are still written [128-dimension][K], so the fragment reads and the MFMA loop do not change.
+template <bool KCONT>
 __device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t ld, int64_t rows, int64_t row0, int64_t k0, float4 (&v)[F4_PER_THREAD]) {
 #pragma unroll
     for (int i = 0; i < F4_PER_THREAD; ++i) {
         const int idx = threadIdx.x + i * NTHREADS;
-        const int row = idx >> 3, c4 = (idx & 7) * 4;
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + row < rows) v[i] = *reinterpret_cast<const float4*>(src + (row0 + row) * ld + k0 + c4);
-    }
-}
-
-__device__ __forceinline__ void store_split(const float4 (&v)[F4_PER_THREAD], unsigned short (*dst)[BM][LDK]) {
-#pragma unroll
-    for (int i = 0; i < F4_PER_THREAD; ++i) {
-        const int idx = threadIdx.x + i * NTHREADS;
-        const int row = idx >> 3, c4 = (idx & 7) * 4;
-        const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-        unsigned short t[3][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) split3_cvt(e[j], t[0][j], t[1][j], t[2][j]);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            uint2 w;
-            w.x = (unsigned)t[p][0] | ((unsigned)t[p][1] << 16);
-            w.y = (unsigned)t[p][2] | ((unsigned)t[p][3] << 16);
-            *reinterpret_cast<uint2*>(&dst[p][row][c4]) = w;
+        if (KCONT) {
+            const int row = idx >> 3, c4 = (idx & 7) * 4;
+            if (row0 + row < rows) v[i] = *reinterpret_cast<const float4*>(src + (row0 + row) * ld + k0 + c4);
+        } else {
+            const int krow = idx >> 5, c4 = (idx & 31) * 4;
+            const float* q = src + (k0 + krow) * ld + row0 + c4;
+            if (row0 + c4 + 3 < rows) v[i] = *reinterpret_cast<const float4*>(q);
+            else {
+                if (row0 + c4 + 0 < rows) v[i].x = q[0];
+                if (row0 + c4 + 1 < rows) v[i].y = q[1];
+                if (row0 + c4 + 2 < rows) v[i].z = q[2];
+            }
         }
     }
 }
 
-template <bool PIPE>
+template <bool KCONT>
+__device__ __forceinline__ void store_split(const float4 (&v)[F4_PER_THREAD], unsigned short (*dst)[BM][LDK]) {
+#pragma unroll
+    for (int i = 0; i < F4_PER_THREAD; ++i) {
+        const int idx = threadIdx.x + i * NTHREADS;
+        const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        unsigned short t[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3_cvt(e[j], t[0][j], t[1][j], t[2][j]);
+        if (KCONT) {
+            const int row = idx >> 3, c4 = (idx & 7) * 4;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                uint2 w;
+                w.x = (unsigned)t[p][0] | ((unsigned)t[p][1] << 16);
+                w.y = (unsigned)t[p][2] | ((unsigned)t[p][3] << 16);
+                *reinterpret_cast<uint2*>(&dst[p][row][c4]) = w;
+            }
+        } else {
+            const int krow = idx >> 5, c4 = (idx & 31) * 4;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[p][c4 + j][krow] = t[p][j];   // transposing 2-byte stores (first form: bank conflicts not yet looked at)
+        }
+    }
+}
+
+// TA: A stored [K][M]; TB: B stored [N][K] (the flags of dyn_gemm_f32).  The first, non-prefetching form exists for X W^T only (!TA, TB).
+template <bool PIPE, bool TA, bool TB>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16x3_nt_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                                   const float* __restrict__ bias, float* __restrict__ C, int64_t M,
                                                                   int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc) {
@@ -134,13 +159,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16x3_nt_kernel(const float* _
             for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
 
     float4 px[F4_PER_THREAD], pw[F4_PER_THREAD];
-    if (PIPE) { load_tile(X, ldx, M, bm, 0, px); load_tile(W, ldw, N, bn, 0, pw); }
+    static_assert(PIPE || (!TA && TB), "the non-prefetching form stages K-contiguous operands only");
+    if (PIPE) { load_tile<!TA>(X, ldx, M, bm, 0, px); load_tile<TB>(W, ldw, N, bn, 0, pw); }
     for (int64_t k0 = 0; k0 < K; k0 += BK) {
         if (PIPE) {
-            store_split(px, sX);
-            store_split(pw, sW);
+            store_split<!TA>(px, sX);
+            store_split<TB>(pw, sW);
             __syncthreads();
-            if (k0 + BK < K) { load_tile(X, ldx, M, bm, k0 + BK, px); load_tile(W, ldw, N, bn, k0 + BK, pw); }   // in flight during the MFMAs below
+            if (k0 + BK < K) { load_tile<!TA>(X, ldx, M, bm, k0 + BK, px); load_tile<TB>(W, ldw, N, bn, k0 + BK, pw); }   // in flight during the MFMAs below
         } else {
             stage_split(X, ldx, M, bm, k0, sX);
             stage_split(W, ldw, N, bn, k0, sW);
@@ -192,22 +218,34 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16x3_nt_kernel(const float* _
 
 }  // namespace
 
-// C[M, N] = X[M, K] . W[N, K]^T (+ bias[N]) in fp32-grade arithmetic on the bf16 matrix cores (see the header of this file: EXPERIMENTAL).
-// K must be a multiple of 32; X, W 16-byte aligned with ldx, ldw multiples of 4 (float4 loads).  Operands must be finite.
+// C[M, N] = op(A) . op(B) (+ bias[N]) in fp32-grade arithmetic on the bf16 matrix cores (see the header of this file: EXPERIMENTAL).
+// trans_a: A stored [K][M]; trans_b: B stored [N][K] (dyn_gemm_f32's flags: the linear layer's forward is (0, 1), its input gradient (0, 0),
+// its weight gradient (1, 0)).  K must be a multiple of 32; A, B 16-byte aligned with lda, ldb multiples of 4.  Operands must be finite.
+// Only (0, 1) in its first form (DYN_BF16X3_VARIANT unset) has run on hardware; every other combination goes through the prefetching form.
+extern "C" int dyn_gemm_bf16x3(int trans_a, int trans_b, const float* A, const float* B, const float* bias, float* C, int64_t M, int64_t N,
+                               int64_t K, int64_t lda, int64_t ldb, int64_t ldc, void* stream) {
+    DYN_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, DYN_E_ARG, "dyn_gemm_bf16x3: bad arguments");
+    DYN_REQUIRE(K % BK == 0, DYN_E_UNSUPPORTED, "dyn_gemm_bf16x3: K = %lld is not a multiple of %d", (long long)K, BK);
+    DYN_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N && lda % 4 == 0 && ldb % 4 == 0 && (((uintptr_t)A) & 15) == 0 &&
+                    (((uintptr_t)B) & 15) == 0,
+                DYN_E_ARG, "dyn_gemm_bf16x3: operands must be 16-byte aligned with leading dimensions that are multiples of 4 and >= the row length");
+    const int64_t gx = dyn::cdiv(N, BN), gy = dyn::cdiv(M, BM);
+    DYN_REQUIRE(gx < 65536 * 16 && gy < 65536, DYN_E_ARG, "dyn_gemm_bf16x3: grid too large");
+    static const int variant = [] { const char* e = getenv("DYN_BF16X3_VARIANT"); return e ? atoi(e) : 1; }();
+    const dim3 grid((unsigned)gx, (unsigned)gy), blk(NTHREADS);
+    hipStream_t st = (hipStream_t)stream;
+#define GO(P, TA_, TB_) hipLaunchKernelGGL((gemm_bf16x3_nt_kernel<P, TA_, TB_>), grid, blk, 0, st, A, B, bias, C, M, N, K, lda, ldb, ldc)
+    if (!trans_a && trans_b) {
+        if (variant == 2) GO(true, false, true);   // prefetching form: written after the round's last GPU run, so it has not executed yet
+        else GO(false, false, true);
+    } else if (!trans_a && !trans_b) GO(true, false, false);
+    else if (trans_a && !trans_b) GO(true, true, false);
+    else GO(true, true, true);
+#undef GO
+    return dyn::check_launch("dyn_gemm_bf16x3");
+}
+
 extern "C" int dyn_gemm_bf16x3_nt(const float* X, const float* W, const float* bias, float* C, int64_t M, int64_t N, int64_t K, int64_t ldx,
                                   int64_t ldw, int64_t ldc, void* stream) {
-    DYN_REQUIRE(X && W && C && M > 0 && N > 0 && K > 0, DYN_E_ARG, "dyn_gemm_bf16x3_nt: bad arguments");
-    DYN_REQUIRE(K % BK == 0, DYN_E_UNSUPPORTED, "dyn_gemm_bf16x3_nt: K = %lld is not a multiple of %d", (long long)K, BK);
-    DYN_REQUIRE(ldx >= K && ldw >= K && ldc >= N && ldx % 4 == 0 && ldw % 4 == 0 && (((uintptr_t)X) & 15) == 0 && (((uintptr_t)W) & 15) == 0,
-                DYN_E_ARG, "dyn_gemm_bf16x3_nt: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
-    const int64_t gx = dyn::cdiv(N, BN), gy = dyn::cdiv(M, BM);
-    DYN_REQUIRE(gx < 65536 * 16 && gy < 65536, DYN_E_ARG, "dyn_gemm_bf16x3_nt: grid too large");
-    static const int variant = [] { const char* e = getenv("DYN_BF16X3_VARIANT"); return e ? atoi(e) : 1; }();
-    if (variant == 2)   // prefetching form: written after the round's last GPU run, so it has not executed yet (see the kernel's comment)
-        hipLaunchKernelGGL(gemm_bf16x3_nt_kernel<true>, dim3((unsigned)gx, (unsigned)gy), dim3(NTHREADS), 0, (hipStream_t)stream, X, W, bias, C, M,
-                           N, K, ldx, ldw, ldc);
-    else
-        hipLaunchKernelGGL(gemm_bf16x3_nt_kernel<false>, dim3((unsigned)gx, (unsigned)gy), dim3(NTHREADS), 0, (hipStream_t)stream, X, W, bias, C, M,
-                           N, K, ldx, ldw, ldc);
-    return dyn::check_launch("dyn_gemm_bf16x3_nt");
+    return dyn_gemm_bf16x3(0, 1, X, W, bias, C, M, N, K, ldx, ldw, ldc, stream);
 }

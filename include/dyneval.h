@@ -97,6 +97,10 @@ int dyn_gemm_f32_grouped(const dyn_gemm_desc* descs, int32_t n, void* workspace,
  * dyn_gemm_f32; scripts/emulate_bf16x3_kernel.py is the lane-level CPU emulation of its indexing. */
 int dyn_gemm_bf16x3_nt(const float* X, const float* W, const float* bias, float* C, int64_t M, int64_t N, int64_t K, int64_t ldx,
                        int64_t ldw, int64_t ldc, void* stream);
+/* The same for C[M, N] = op(A) . op(B) with dyn_gemm_f32's transpose flags (trans_a: A stored [K][M]; trans_b: B stored [N][K]): the linear layer's
+ * input gradient is (0, 0), its weight gradient (1, 0) (loss.backward(), reference lcasr/lib.py:579).  Only (0, 1) has run on hardware so far. */
+int dyn_gemm_bf16x3(int trans_a, int trans_b, const float* A, const float* B, const float* bias, float* C, int64_t M, int64_t N, int64_t K,
+                    int64_t lda, int64_t ldb, int64_t ldc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HBM-bound encoder pieces (activations, norms, softmax, convolutions).  All replace ops inside

@@ -40,6 +40,23 @@ def stage_split(src, rows, row0, k0):
     return dst
 
 
+def stage_split_t(src, rows, row0, k0):
+    """The !KCONT staging of the prefetching form: the source is stored [K][128-dimension]; float4 along the 128-dimension (guarded element-wise at
+    the ragged edge), planes written transposed [128-dimension][K]."""
+    dst = np.zeros((3, BM, BK), np.uint16)
+    for idx in range(BM * BK // 4):
+        krow, c4 = idx >> 5, (idx & 31) * 4
+        v = np.zeros(4, np.float32)
+        for j in range(4):
+            if row0 + c4 + j < rows:
+                v[j] = src[k0 + krow, row0 + c4 + j]
+        t = split3(v)
+        for p in range(3):
+            for j in range(4):
+                dst[p, c4 + j, krow] = t[p][j]
+    return dst
+
+
 def mfma_32x32x16(a_lanes, b_lanes, acc_lanes):
     """a_lanes, b_lanes: [64][8] bf16 values as float32; acc_lanes: [64][16] float32 (updated in place, float32 accumulation)."""
     A = np.zeros((32, 16), np.float64)
@@ -56,14 +73,16 @@ def mfma_32x32x16(a_lanes, b_lanes, acc_lanes):
             acc_lanes[lane, q] = np.float32(np.float64(acc_lanes[lane, q]) + D[row, r])
 
 
-def kernel(X, W, bias, M, N, K):
+def kernel(X, W, bias, M, N, K, ta=False, tb=True):
+    """X: A as stored ([M][K], or [K][M] when ta); W: B as stored ([N][K] when tb, else [K][N])."""
     C = np.full((M, N), np.nan, np.float32)
     for by in range(-(-M // BM)):
         for bx in range(-(-N // BN)):
             bm, bn = by * BM, bx * BN
             acc = np.zeros((4, 2, 2, 64, 16), np.float32)          # [wave][mi][ni][lane][reg]
             for k0 in range(0, K, BK):
-                sX, sW = stage_split(X, M, bm, k0), stage_split(W, N, bn, k0)
+                sX = stage_split_t(X, M, bm, k0) if ta else stage_split(X, M, bm, k0)
+                sW = stage_split(W, N, bn, k0) if tb else stage_split_t(W, N, bn, k0)
                 for wave in range(4):
                     wm, wn = (wave >> 1) * 64, (wave & 1) * 64
                     for ks in range(BK // 16):
@@ -107,6 +126,16 @@ def main():
         assert not np.isnan(got).any(), "an output element was never written"
         err = np.abs(got - ref).max() / np.abs(ref).max()
         print(f"M={M} N={N} K={K} bias={with_bias}: max |err| / max |C| = {err:.2e}", flush=True)
+        assert err < 2e-6, err
+    # the other transpose forms of the prefetching kernel (dyn_gemm_bf16x3): operands stored transposed, staged through stage_split_t
+    for M, N, K, ta, tb in ((150, 200, 64, False, False), (130, 131, 32, True, False), (33, 129, 64, True, True)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        B = (rng.standard_normal((K, N)) * 0.1).astype(np.float32)
+        got = kernel(np.ascontiguousarray(A.T) if ta else A, np.ascontiguousarray(B.T) if tb else B, None, M, N, K, ta, tb)
+        ref = A.astype(np.float64) @ B.astype(np.float64)
+        assert not np.isnan(got).any()
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        print(f"M={M} N={N} K={K} trans_a={ta} trans_b={tb}: max |err| / max |C| = {err:.2e}", flush=True)
         assert err < 2e-6, err
     print("emulation matches float64 within fp32 rounding: the kernel's indexing is consistent with the documented MFMA layouts")
 

@@ -1,5 +1,6 @@
 """EXPERIMENTAL (round 5 starts here): time dyn_gemm_bf16x3_nt against dyn_gemm_f32 on the path's linear-layer shapes and print the error of both
-against float64.  python scripts/probe_gemm_bf16x3.py   (GPU box)"""
+against float64.  python scripts/probe_gemm_bf16x3.py   (GPU box; DYN_BF16X3_VARIANT=2 selects the prefetching form, `all` as an argument also times
+the input-gradient (0, 0) and weight-gradient (1, 0) forms, which have not run on hardware yet)"""
 import os
 import sys
 
@@ -34,3 +35,16 @@ for M, N, K in ((4096, 768, 768), (4096, 3072, 768), (4096, 768, 3072), (4096, 2
     fl = 2.0 * M * N * K
     print(f"{M}x{N}x{K}: bf16x3 {t3 * 1e3:.1f} us = {fl / t3 / 1e9:.1f} TFLOP/s fp32-equivalent (err {(c3.double() - ref).abs().max().item() / s:.1e}) | "
           f"dyn_gemm_f32 {t1 * 1e3:.1f} us = {fl / t1 / 1e9:.1f} TFLOP/s (err {(c1.double() - ref).abs().max().item() / s:.1e})", flush=True)
+
+if len(sys.argv) > 1 and sys.argv[1] == "all":
+    for M, N, K, ta, tb in ((4096, 768, 768, 0, 0), (4096, 768, 3072, 0, 0), (16384, 768, 3072, 0, 0), (768, 768, 4096, 1, 0), (3072, 768, 4096, 1, 0), (768, 3072, 16384, 1, 0)):
+        a, b = torch.randn(M, K, device=dev), torch.randn(K, N, device=dev) * 0.05
+        A, B = (a.t().contiguous() if ta else a), (b.t().contiguous() if tb else b)
+        c3, c1, st = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev), torch.cuda.current_stream().cuda_stream
+        t3 = timeit(lambda: check(load().dyn_gemm_bf16x3(ta, tb, A.data_ptr(), B.data_ptr(), None, c3.data_ptr(), M, N, K, A.shape[1], B.shape[1], N, st), "bf16x3"))
+        t1 = timeit(lambda: ops.gemm(A, B, c1, trans_a=bool(ta), trans_b=bool(tb), M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N))
+        ref = a.double() @ b.double()
+        s = ref.abs().max().item()
+        fl = 2.0 * M * N * K
+        print(f"ta={ta} tb={tb} {M}x{N}x{K}: bf16x3 {t3 * 1e3:.1f} us = {fl / t3 / 1e9:.1f} TFLOP/s fp32-equivalent (err {(c3.double() - ref).abs().max().item() / s:.1e}) | "
+              f"dyn_gemm_f32 {t1 * 1e3:.1f} us = {fl / t1 / 1e9:.1f} TFLOP/s (err {(c1.double() - ref).abs().max().item() / s:.1e})", flush=True)

@@ -27,3 +27,30 @@ def test_bf16x3_product_is_fp32_grade(cuda, M, N, K, bias):
     e3, e1 = (c.double() - ref).abs().max().item() / scale, (f32.double() - ref).abs().max().item() / scale
     print(f"M={M} N={N} K={K}: |bf16x3 - f64| {e3:.2e}, |dyn_gemm_f32 - f64| {e1:.2e} (relative to max |C|)")
     assert e3 < 2 * e1 + 1.2e-7, (e3, e1)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("DYN_EXPERIMENTAL") != "1",
+                    reason="the transposed forms / the prefetching form of the bf16x3 kernel were written after the round's last GPU run: opt-in (DYN_EXPERIMENTAL=1)")
+@pytest.mark.parametrize("M,N,K,ta,tb", [(150, 200, 64, 0, 0), (130, 131, 32, 1, 0), (33, 129, 64, 1, 1), (4096, 768, 768, 0, 0), (768, 3072, 4096, 1, 0),
+                                         (4096, 768, 768, 0, 1)])
+def test_bf16x3_transpose_forms(cuda, M, N, K, ta, tb):
+    """dyn_gemm_bf16x3 with dyn_gemm_f32's transpose flags: (0, 0) = the linear layer's input gradient, (1, 0) = its weight gradient (K = frames).
+    With DYN_BF16X3_VARIANT=2 the (0, 1) case runs the prefetching form too."""
+    from dynamic_asr_eval_amd import ops
+    from dynamic_asr_eval_amd._lib import check, load
+    g = torch.Generator().manual_seed(M + N + K + ta + 2 * tb)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g) * 0.1
+    A = (a.t().contiguous() if ta else a).to(cuda)
+    B = (b.t().contiguous() if tb else b).to(cuda)
+    c = torch.full((M, N), float("nan"), device=cuda)
+    check(load().dyn_gemm_bf16x3(ta, tb, A.data_ptr(), B.data_ptr(), None, c.data_ptr(), M, N, K, A.shape[1], B.shape[1], N,
+                                 torch.cuda.current_stream().cuda_stream), "dyn_gemm_bf16x3")
+    ref = a.double() @ b.double()
+    f32 = torch.empty(M, N, device=cuda)
+    ops.gemm(A, B, f32, trans_a=bool(ta), trans_b=bool(tb), M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N)
+    assert torch.isfinite(c).all()
+    scale = ref.abs().max().item()
+    e3, e1 = (c.cpu().double() - ref).abs().max().item() / scale, (f32.cpu().double() - ref).abs().max().item() / scale
+    print(f"M={M} N={N} K={K} ta={ta} tb={tb}: |bf16x3 - f64| {e3:.2e}, |dyn_gemm_f32 - f64| {e1:.2e}")
+    assert e3 < 2 * e1 + 1.2e-7, (e3, e1)
