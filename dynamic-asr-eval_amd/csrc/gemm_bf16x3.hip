@@ -139,8 +139,56 @@ __device__ __forceinline__ void store_split(const float4 (&v)[F4_PER_THREAD], un
     }
 }
 
+// ---- pre-split B operand (NOT YET RUN ON HARDWARE): the weights change once per optimiser step, so their three bf16 planes can be written once
+// per step (dyn_bf16x3_split; or by the optimiser kernel itself) instead of being split by every workgroup that stages them — that halves the
+// split work on the critical path and makes the B stage a plain 16-byte copy.  Planes: unsigned short [3][rows][K], K contiguous.
+constexpr int U4_PER_THREAD = (3 * BN * BK * 2 / 16) / NTHREADS;   // 1536 16-byte pieces per tile, 6 per thread
+
+__device__ __forceinline__ void load_planes(const unsigned short* __restrict__ planes, int64_t rows, int64_t K, int64_t row0, int64_t k0,
+                                            uint4 (&v)[U4_PER_THREAD]) {
+#pragma unroll
+    for (int i = 0; i < U4_PER_THREAD; ++i) {
+        const int idx = threadIdx.x + i * NTHREADS;          // 0 .. 1535
+        const int p = idx >> 9, rem = idx & 511;             // 512 pieces per plane
+        const int row = rem >> 2, c8 = (rem & 3) * 8;
+        v[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (row0 + row < rows) v[i] = *reinterpret_cast<const uint4*>(planes + ((int64_t)p * rows + row0 + row) * K + k0 + c8);
+    }
+}
+
+__device__ __forceinline__ void store_planes(const uint4 (&v)[U4_PER_THREAD], unsigned short (*dst)[BN][LDK]) {
+#pragma unroll
+    for (int i = 0; i < U4_PER_THREAD; ++i) {
+        const int idx = threadIdx.x + i * NTHREADS;
+        const int p = idx >> 9, rem = idx & 511;
+        const int row = rem >> 2, c8 = (rem & 3) * 8;
+        *reinterpret_cast<uint4*>(&dst[p][row][c8]) = v[i];   // 16-B aligned: row stride 80 B, c8 * 2 B in {0, 16, 32, 48}
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS) void bf16x3_split_kernel(const float* __restrict__ src, unsigned short* __restrict__ planes, int64_t rows,
+                                                                int64_t K, int64_t ld) {
+    const int64_t n4 = rows * (K / 4);
+    for (int64_t i = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NTHREADS) {
+        const int64_t row = i / (K / 4), c4 = (i % (K / 4)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + row * ld + c4);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        unsigned short t[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3_cvt(e[j], t[0][j], t[1][j], t[2][j]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            uint2 w;
+            w.x = (unsigned)t[p][0] | ((unsigned)t[p][1] << 16);
+            w.y = (unsigned)t[p][2] | ((unsigned)t[p][3] << 16);
+            *reinterpret_cast<uint2*>(planes + ((int64_t)p * rows + row) * K + c4) = w;
+        }
+    }
+}
+
 // TA: A stored [K][M]; TB: B stored [N][K] (the flags of dyn_gemm_f32).  The first, non-prefetching form exists for X W^T only (!TA, TB).
-template <bool PIPE, bool TA, bool TB>
+// BPRE: B comes as pre-split planes [3][N][K] (W is then that pointer; needs PIPE, !TA-or-TA as usual, TB).
+template <bool PIPE, bool TA, bool TB, bool BPRE = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16x3_nt_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                                   const float* __restrict__ bias, float* __restrict__ C, int64_t M,
                                                                   int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldc) {
@@ -159,14 +207,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16x3_nt_kernel(const float* _
             for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
 
     float4 px[F4_PER_THREAD], pw[F4_PER_THREAD];
+    uint4 pp[U4_PER_THREAD];
     static_assert(PIPE || (!TA && TB), "the non-prefetching form stages K-contiguous operands only");
-    if (PIPE) { load_tile<!TA>(X, ldx, M, bm, 0, px); load_tile<TB>(W, ldw, N, bn, 0, pw); }
+    static_assert(!BPRE || (PIPE && TB), "pre-split B planes are [N][K] and go through the prefetching form");
+    const unsigned short* Wp = reinterpret_cast<const unsigned short*>(W);
+    if (PIPE) {
+        load_tile<!TA>(X, ldx, M, bm, 0, px);
+        if (BPRE) load_planes(Wp, N, K, bn, 0, pp);
+        else load_tile<TB>(W, ldw, N, bn, 0, pw);
+    }
     for (int64_t k0 = 0; k0 < K; k0 += BK) {
         if (PIPE) {
             store_split<!TA>(px, sX);
-            store_split<TB>(pw, sW);
+            if (BPRE) store_planes(pp, sW);
+            else store_split<TB>(pw, sW);
             __syncthreads();
-            if (k0 + BK < K) { load_tile<!TA>(X, ldx, M, bm, k0 + BK, px); load_tile<TB>(W, ldw, N, bn, k0 + BK, pw); }   // in flight during the MFMAs below
+            if (k0 + BK < K) {   // in flight during the MFMAs below
+                load_tile<!TA>(X, ldx, M, bm, k0 + BK, px);
+                if (BPRE) load_planes(Wp, N, K, bn, k0 + BK, pp);
+                else load_tile<TB>(W, ldw, N, bn, k0 + BK, pw);
+            }
         } else {
             stage_split(X, ldx, M, bm, k0, sX);
             stage_split(W, ldw, N, bn, k0, sW);
@@ -248,4 +308,29 @@ extern "C" int dyn_gemm_bf16x3(int trans_a, int trans_b, const float* A, const f
 extern "C" int dyn_gemm_bf16x3_nt(const float* X, const float* W, const float* bias, float* C, int64_t M, int64_t N, int64_t K, int64_t ldx,
                                   int64_t ldw, int64_t ldc, void* stream) {
     return dyn_gemm_bf16x3(0, 1, X, W, bias, C, M, N, K, ldx, ldw, ldc, stream);
+}
+
+// planes [3][rows][K] (unsigned short, K contiguous) <- the three bf16 terms of src [rows][K] (ld >= K, multiple of 4; K % 4 == 0).  NOT YET RUN.
+extern "C" int dyn_bf16x3_split(const float* src, void* planes, int64_t rows, int64_t K, int64_t ld, void* stream) {
+    DYN_REQUIRE(src && planes && rows > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 4 == 0 && (((uintptr_t)src) & 15) == 0 &&
+                    (((uintptr_t)planes) & 15) == 0,
+                DYN_E_ARG, "dyn_bf16x3_split: bad arguments");
+    int64_t g = dyn::cdiv(rows * (K / 4), NTHREADS);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(bf16x3_split_kernel, dim3((unsigned)g), dim3(NTHREADS), 0, (hipStream_t)stream, src, (unsigned short*)planes, rows, K, ld);
+    return dyn::check_launch("dyn_bf16x3_split");
+}
+
+// C[M, N] = X[M, K] . W^T (+ bias) with W given as the pre-split planes of dyn_bf16x3_split (rows = N).  K % 32 == 0.  NOT YET RUN.
+extern "C" int dyn_gemm_bf16x3_presplit(const float* X, const void* w_planes, const float* bias, float* C, int64_t M, int64_t N, int64_t K,
+                                        int64_t ldx, int64_t ldc, void* stream) {
+    DYN_REQUIRE(X && w_planes && C && M > 0 && N > 0 && K > 0, DYN_E_ARG, "dyn_gemm_bf16x3_presplit: bad arguments");
+    DYN_REQUIRE(K % BK == 0, DYN_E_UNSUPPORTED, "dyn_gemm_bf16x3_presplit: K = %lld is not a multiple of %d", (long long)K, BK);
+    DYN_REQUIRE(ldx >= K && ldc >= N && ldx % 4 == 0 && (((uintptr_t)X) & 15) == 0 && (((uintptr_t)w_planes) & 15) == 0, DYN_E_ARG,
+                "dyn_gemm_bf16x3_presplit: operands must be 16-byte aligned, ldx a multiple of 4");
+    const int64_t gx = dyn::cdiv(N, BN), gy = dyn::cdiv(M, BM);
+    DYN_REQUIRE(gx < 65536 * 16 && gy < 65536, DYN_E_ARG, "dyn_gemm_bf16x3_presplit: grid too large");
+    hipLaunchKernelGGL((gemm_bf16x3_nt_kernel<true, false, true, true>), dim3((unsigned)gx, (unsigned)gy), dim3(NTHREADS), 0, (hipStream_t)stream, X,
+                       (const float*)w_planes, bias, C, M, N, K, ldx, K, ldc);
+    return dyn::check_launch("dyn_gemm_bf16x3_presplit");
 }

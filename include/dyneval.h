@@ -101,6 +101,12 @@ int dyn_gemm_bf16x3_nt(const float* X, const float* W, const float* bias, float*
  * input gradient is (0, 0), its weight gradient (1, 0) (loss.backward(), reference lcasr/lib.py:579).  Only (0, 1) has run on hardware so far. */
 int dyn_gemm_bf16x3(int trans_a, int trans_b, const float* A, const float* B, const float* bias, float* C, int64_t M, int64_t N, int64_t K,
                     int64_t lda, int64_t ldb, int64_t ldc, void* stream);
+/* EXPERIMENTAL, not yet run on hardware: the weight operand split once (planes = unsigned short [3][rows][K], K contiguous: the three bf16 terms of
+ * src [rows][K]) instead of by every workgroup that stages it, and X W^T (+ bias) on those planes (rows = N).  The weights change once per
+ * optimiser step (reference lcasr/lib.py:580), so the split is one HBM pass per step. */
+int dyn_bf16x3_split(const float* src, void* planes, int64_t rows, int64_t K, int64_t ld, void* stream);
+int dyn_gemm_bf16x3_presplit(const float* X, const void* w_planes, const float* bias, float* C, int64_t M, int64_t N, int64_t K, int64_t ldx,
+                             int64_t ldc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HBM-bound encoder pieces (activations, norms, softmax, convolutions).  All replace ops inside

@@ -57,6 +57,23 @@ def stage_split_t(src, rows, row0, k0):
     return dst
 
 
+def split_planes(src):
+    """dyn_bf16x3_split: [3][rows][K] planes of src [rows][K]."""
+    t = split3(src.reshape(-1))
+    return np.stack([x.reshape(src.shape) for x in t])
+
+
+def stage_planes(planes, rows, row0, k0):
+    """The pre-split B stage (load_planes / store_planes): 1536 16-byte pieces per tile, plane-major."""
+    dst = np.zeros((3, BM, BK), np.uint16)
+    for idx in range(3 * BM * BK * 2 // 16):
+        p, rem = idx >> 9, idx & 511
+        row, c8 = rem >> 2, (rem & 3) * 8
+        if row0 + row < rows:
+            dst[p, row, c8:c8 + 8] = planes[p, row0 + row, k0 + c8:k0 + c8 + 8]
+    return dst
+
+
 def mfma_32x32x16(a_lanes, b_lanes, acc_lanes):
     """a_lanes, b_lanes: [64][8] bf16 values as float32; acc_lanes: [64][16] float32 (updated in place, float32 accumulation)."""
     A = np.zeros((32, 16), np.float64)
@@ -73,8 +90,8 @@ def mfma_32x32x16(a_lanes, b_lanes, acc_lanes):
             acc_lanes[lane, q] = np.float32(np.float64(acc_lanes[lane, q]) + D[row, r])
 
 
-def kernel(X, W, bias, M, N, K, ta=False, tb=True):
-    """X: A as stored ([M][K], or [K][M] when ta); W: B as stored ([N][K] when tb, else [K][N])."""
+def kernel(X, W, bias, M, N, K, ta=False, tb=True, bpre=False):
+    """X: A as stored ([M][K], or [K][M] when ta); W: B as stored ([N][K] when tb, else [K][N]); bpre: W is the pre-split planes [3][N][K]."""
     C = np.full((M, N), np.nan, np.float32)
     for by in range(-(-M // BM)):
         for bx in range(-(-N // BN)):
@@ -82,7 +99,7 @@ def kernel(X, W, bias, M, N, K, ta=False, tb=True):
             acc = np.zeros((4, 2, 2, 64, 16), np.float32)          # [wave][mi][ni][lane][reg]
             for k0 in range(0, K, BK):
                 sX = stage_split_t(X, M, bm, k0) if ta else stage_split(X, M, bm, k0)
-                sW = stage_split(W, N, bn, k0) if tb else stage_split_t(W, N, bn, k0)
+                sW = stage_planes(W, N, bn, k0) if bpre else (stage_split(W, N, bn, k0) if tb else stage_split_t(W, N, bn, k0))
                 for wave in range(4):
                     wm, wn = (wave >> 1) * 64, (wave & 1) * 64
                     for ks in range(BK // 16):
@@ -136,6 +153,16 @@ def main():
         assert not np.isnan(got).any()
         err = np.abs(got - ref).max() / np.abs(ref).max()
         print(f"M={M} N={N} K={K} trans_a={ta} trans_b={tb}: max |err| / max |C| = {err:.2e}", flush=True)
+        assert err < 2e-6, err
+    # pre-split weight planes (dyn_bf16x3_split + dyn_gemm_bf16x3_presplit)
+    for M, N, K in ((150, 200, 64), (33, 129, 32)):
+        X = rng.standard_normal((M, K)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) * 0.1).astype(np.float32)
+        got = kernel(X, split_planes(W), None, M, N, K, False, True, True)
+        ref = X.astype(np.float64) @ W.astype(np.float64).T
+        assert not np.isnan(got).any()
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        print(f"M={M} N={N} K={K} pre-split W planes: max |err| / max |C| = {err:.2e}", flush=True)
         assert err < 2e-6, err
     print("emulation matches float64 within fp32 rounding: the kernel's indexing is consistent with the documented MFMA layouts")
 

@@ -54,3 +54,25 @@ def test_bf16x3_transpose_forms(cuda, M, N, K, ta, tb):
     e3, e1 = (c.cpu().double() - ref).abs().max().item() / scale, (f32.cpu().double() - ref).abs().max().item() / scale
     print(f"M={M} N={N} K={K} ta={ta} tb={tb}: |bf16x3 - f64| {e3:.2e}, |dyn_gemm_f32 - f64| {e1:.2e}")
     assert e3 < 2 * e1 + 1.2e-7, (e3, e1)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("DYN_EXPERIMENTAL") != "1", reason="pre-split weight planes: written after the round's last GPU run (DYN_EXPERIMENTAL=1)")
+@pytest.mark.parametrize("M,N,K", [(150, 200, 64), (33, 129, 32), (4096, 768, 768), (4096, 3072, 768)])
+def test_bf16x3_presplit_weight_planes(cuda, M, N, K):
+    """dyn_bf16x3_split (the three bf16 terms of W as planes, exact: their sum is W) + dyn_gemm_bf16x3_presplit = dyn_gemm_bf16x3_nt's result."""
+    from dynamic_asr_eval_amd._lib import check, load
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(cuda)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(cuda)
+    planes = torch.empty(3, N, K, dtype=torch.int16, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    check(load().dyn_bf16x3_split(w.data_ptr(), planes.data_ptr(), N, K, K, st), "dyn_bf16x3_split")
+    terms = ((planes.to(torch.int32) & 0xFFFF) << 16).view(torch.float32)      # bf16 bits -> the fp32 values they stand for
+    back = terms.double().sum(0)
+    assert torch.equal(back.float(), w), "the three bf16 terms must add up to the fp32 value exactly"
+    c = torch.full((M, N), float("nan"), device=cuda)
+    check(load().dyn_gemm_bf16x3_presplit(x.data_ptr(), planes.data_ptr(), None, c.data_ptr(), M, N, K, K, N, st), "dyn_gemm_bf16x3_presplit")
+    ref = x.double() @ w.double().t()
+    err = (c.double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"M={M} N={N} K={K} pre-split: |bf16x3 - f64| {err:.2e}")
+    assert torch.isfinite(c).all() and err < 3e-6
