@@ -48,3 +48,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "all":
         fl = 2.0 * M * N * K
         print(f"ta={ta} tb={tb} {M}x{N}x{K}: bf16x3 {t3 * 1e3:.1f} us = {fl / t3 / 1e9:.1f} TFLOP/s fp32-equivalent (err {(c3.double() - ref).abs().max().item() / s:.1e}) | "
               f"dyn_gemm_f32 {t1 * 1e3:.1f} us = {fl / t1 / 1e9:.1f} TFLOP/s (err {(c1.double() - ref).abs().max().item() / s:.1e})", flush=True)
+    # pre-split weight planes: the B stage becomes a copy, only X is split by the workgroups
+    for M, N, K in ((4096, 768, 768), (4096, 3072, 768), (16384, 768, 768), (16384, 3072, 768)):
+        x, w = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) * 0.05
+        planes, c3, st = torch.empty(3, N, K, dtype=torch.int16, device=dev), torch.empty(M, N, device=dev), torch.cuda.current_stream().cuda_stream
+        ts = timeit(lambda: check(load().dyn_bf16x3_split(w.data_ptr(), planes.data_ptr(), N, K, K, st), "split"))
+        t3 = timeit(lambda: check(load().dyn_gemm_bf16x3_presplit(x.data_ptr(), planes.data_ptr(), None, c3.data_ptr(), M, N, K, K, N, st), "presplit"))
+        ref = x.double() @ w.double().t()
+        fl = 2.0 * M * N * K
+        print(f"pre-split {M}x{N}x{K}: split of W {ts * 1e3:.1f} us, product {t3 * 1e3:.1f} us = {fl / t3 / 1e9:.1f} TFLOP/s fp32-equivalent "
+              f"(err {(c3.double() - ref).abs().max().item() / ref.abs().max().item():.1e})", flush=True)
