@@ -1,4 +1,4 @@
-// EXPERIMENTAL — not on the product path: nothing but tests/test_gemm_bf16x3_gpu.py and scripts/probe_gemm_bf16x3.py calls it (DESIGN.md section 6,
+// EXPERIMENTAL — not on the product path: nothing but tests/test_zz_experimental_bf16x3_gpu.py and scripts/probe_gemm_bf16x3.py calls it (DESIGN.md section 6,
 // "where the next factor is").
 //
 // An fp32 GEMM on the bf16 matrix cores by OPERAND SPLITTING: every fp32 operand is exactly the sum of three bf16 terms (3 x 8 significant
@@ -9,7 +9,7 @@
 //
 // This file is the first, correctness-first form of that kernel, written at the end of round 4: its index arithmetic was checked by a lane-level
 // emulation on the CPU (scripts/emulate_bf16x3_kernel.py), then it ran on the MI355X with the round's last GPU seconds
-// (tests/test_gemm_bf16x3_gpu.py: five shapes, each closer to float64 than dyn_gemm_f32; scripts/probe_gemm_bf16x3.py: 83 - 108 TFLOP/s
+// (tests/test_zz_experimental_bf16x3_gpu.py: five shapes, each closer to float64 than dyn_gemm_f32; scripts/probe_gemm_bf16x3.py: 83 - 108 TFLOP/s
 // fp32-equivalent at M >= 8192 against 120 - 131 for the tuned fp32 kernel — profiles/r04_bf16x3_kernel_first_*.log).
 // Shape: C[M, N] = X[M, K] . W[N, K]^T (+ bias[N]) — the `linear` layout of the path (reference: every nn.Linear inside
 // model(audio_signal=...), lcasr/lib.py:550), both operands K-contiguous, which is also what the MFMA fragment wants: lane (r = l & 31,

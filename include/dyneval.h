@@ -93,7 +93,7 @@ int dyn_gemm_f32_grouped(const dyn_gemm_desc* descs, int32_t n, void* workspace,
 /* EXPERIMENTAL (not on the product path): C[M, N] = X[M, K] . W[N, K]^T (+ bias[N]) as an fp32-grade product on the bf16
  * matrix cores — every fp32 operand split into three bf16 terms, six v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulation
  * (the nn.Linear products inside model(audio_signal=...), reference lcasr/lib.py:550).  K % 32 == 0, X / W 16-byte aligned, ldx / ldw
- * multiples of 4, finite operands.  First, unpipelined form (end of round 4): tests/test_gemm_bf16x3_gpu.py holds it to float64 next to
+ * multiples of 4, finite operands.  First, unpipelined form (end of round 4): tests/test_zz_experimental_bf16x3_gpu.py holds it to float64 next to
  * dyn_gemm_f32; scripts/emulate_bf16x3_kernel.py is the lane-level CPU emulation of its indexing. */
 int dyn_gemm_bf16x3_nt(const float* X, const float* W, const float* bias, float* C, int64_t M, int64_t N, int64_t K, int64_t ldx,
                        int64_t ldw, int64_t ldc, void* stream);

@@ -3,7 +3,7 @@ into three bf16 planes, the per-lane fragment addresses, the six MFMAs per tile 
 v_mfma_f32_32x32x16_bf16 modelled from the operand / result layouts of /opt/skills/guides/cdna_hip_programming.md (A: lane (r = l & 31, h = l >> 5)
 holds A[row r][k = 8h + j]; B: B[k = 8h + j][col r]; D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)).  Checks the result against
 float64 X W^T (+ bias) on ragged sizes.  What it proves: the kernel's indexing is consistent with the documented layouts; what it cannot prove:
-that the hardware agrees — that is tests/test_gemm_bf16x3_gpu.py's job (it did: profiles/r04_bf16x3_kernel_first_run.log).
+that the hardware agrees — that is tests/test_zz_experimental_bf16x3_gpu.py's job (it did: profiles/r04_bf16x3_kernel_first_run.log).
     python scripts/emulate_bf16x3_kernel.py"""
 import numpy as np
 

@@ -2,7 +2,8 @@
 splitting.  Not on the product path.  The kernel was written at the end of round 4 against a lane-level CPU emulation of the MFMA layouts and
 then ran once on the MI355X with the round's last GPU seconds (profiles/r04_bf16x3_kernel_first_run.log: these five cases, every one closer to
 float64 than dyn_gemm_f32).  Bar: against float64, no further from it than twice the path's own fp32 GEMM (dyn_gemm_f32) plus one fp32 ulp of
-the largest output — the emulations (scripts/probe_bf16x3_numerics.py) put it at 1.5 - 2x, the hardware below 1x."""
+the largest output — the emulations (scripts/probe_bf16x3_numerics.py) put it at 1.5 - 2x, the hardware below 1x.
+(The file name sorts last on purpose: the suite runs with -x, and an experimental kernel must not be able to hide the product path's tests.)"""
 import pytest
 import torch
 
