@@ -37,7 +37,8 @@ __device__ __forceinline__ unsigned short bf16_bits(float x) {
 }
 __device__ __forceinline__ float bf16_value(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 
-// x = t0 + t1 + t2 exactly (each residual is exact in fp32: the subtrahend is x's leading bits)
+// x = t0 + t1 + t2 exactly for |x| >= 2^-95 (each residual is exact in fp32: the subtrahend is x's leading bits; below ~2^-102 the third term
+// would be a bf16 subnormal and the sum is off by < 2^-133 absolute — tests/test_host_cpu.py::test_bf16x3_split_is_exact_on_the_host_emulation)
 __device__ __forceinline__ void split3(float x, unsigned short& t0, unsigned short& t1, unsigned short& t2) {
     t0 = bf16_bits(x);
     const float r1 = x - bf16_value(t0);

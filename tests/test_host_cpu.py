@@ -464,3 +464,23 @@ def test_wav2vec2_length_buckets_host_arithmetic():
         assert T == me.conv_lengths(L)[-1] and Tb % 32 == 0 and Tb - 32 < T <= Tb and Lb >= L
         assert me.conv_lengths(Lb)[-1] == Tb and me.conv_lengths(Lb + 1)[-1] == Tb + 1
         assert all(v <= b for v, b in zip(me.conv_lengths(L), me.conv_lengths(Lb)))      # every layer's valid frames fit the static shape
+
+
+def test_bf16x3_split_is_exact_on_the_host_emulation():
+    """The operand split of the experimental bf16x3 GEMM (csrc/gemm_bf16x3.hip, emulated in scripts/emulate_bf16x3_kernel.py): every finite fp32
+    value of magnitude >= 2^-95 is EXACTLY the sum of its three round-to-nearest-even bf16 terms (3 x 8 significant bits cover the 24), also for
+    negative and power-of-two values; what the kernel drops is products, never operand bits.  (Below ~2^-102 the third term would be a bf16
+    subnormal and the sum is off by < 2^-133 absolute: far under anything an activation or weight of this model carries.)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("emu", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "emulate_bf16x3_kernel.py"))
+    emu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(emu)
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(200000).astype(np.float32) * s for s in (1e-6, 1.0, 1e6, 1e30)] +
+                       [np.array([0.0, -0.0, 1.0, -1.0, 2.0 ** -90, 2.0 ** 100, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.0e38, -65504.0], np.float32),
+                        rng.integers(0x10000000, 0x7F000000, 200000, dtype=np.uint32).view(np.float32)])
+    x = x[(x == 0) | (np.abs(x) >= 2.0 ** -95)]
+    t0, t1, t2 = emu.split3(x)
+    total = emu.bf16_value(t0).astype(np.float64) + emu.bf16_value(t1).astype(np.float64) + emu.bf16_value(t2).astype(np.float64)
+    assert np.array_equal(total, x.astype(np.float64))
